@@ -1,0 +1,104 @@
+"""ctypes binding of libjsim_mpc.so (include/jsim_mpc.h).  Thin: pointers + sizes only.
+
+The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded this module
+raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .config import MPCConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjsim_mpc.so")
+ABI_VERSION = 1
+
+
+class JsimCfg(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("max_iter", C.c_int32),
+        ("dt", C.c_double), ("dl", C.c_double), ("L", C.c_double),
+        ("w_perp", C.c_double), ("w_para", C.c_double),
+        ("R", C.c_double * 2), ("Rd", C.c_double * 2), ("Q_v_yaw", C.c_double * 2),
+        ("Qf", C.c_double * 4), ("R_end", C.c_double * 2),
+        ("max_dsteer", C.c_double), ("max_accel", C.c_double), ("max_decel", C.c_double),
+        ("max_steer", C.c_double), ("max_speed", C.c_double), ("min_speed", C.c_double),
+        ("min_ref_speed", C.c_double), ("goal_dis", C.c_double), ("stop_speed", C.c_double),
+    ]
+
+
+EXPORTS = (
+    "jsim_abi_version", "jsim_last_error", "jsim_mpc_create", "jsim_mpc_destroy", "jsim_mpc_set_paths",
+    "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_mpc_xref_deviation_goal",
+)
+
+_lib = None
+
+
+class JsimError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JsimError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "The MPC path is HIP-only; there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    lib.jsim_abi_version.restype = C.c_int
+    lib.jsim_abi_version.argtypes = []
+    lib.jsim_last_error.restype = C.c_char_p
+    lib.jsim_last_error.argtypes = [vp]
+    lib.jsim_mpc_create.restype = C.c_int
+    lib.jsim_mpc_create.argtypes = [C.POINTER(JsimCfg), C.c_int, C.POINTER(vp)]
+    lib.jsim_mpc_destroy.restype = None
+    lib.jsim_mpc_destroy.argtypes = [vp]
+    lib.jsim_mpc_set_paths.restype = C.c_int
+    lib.jsim_mpc_set_paths.argtypes = [vp, vp, vp, vp, vp, i32]
+    lib.jsim_mpc_step.restype = C.c_int
+    lib.jsim_mpc_step.argtypes = [vp, i32] + [vp] * 16
+    lib.jsim_mpc_step_debug.restype = C.c_int
+    lib.jsim_mpc_step_debug.argtypes = [vp, i32] + [vp] * 21
+    lib.jsim_plant_step.restype = C.c_int
+    lib.jsim_plant_step.argtypes = [vp, i32] + [vp] * 6
+    lib.jsim_mpc_xref_deviation_goal.restype = C.c_int
+    lib.jsim_mpc_xref_deviation_goal.argtypes = [vp, i32] + [vp] * 9
+    if lib.jsim_abi_version() != ABI_VERSION:
+        raise JsimError(f"libjsim_mpc.so ABI {lib.jsim_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def make_cfg(config: MPCConfig, T: int, dt: float, dl: float, L: float) -> JsimCfg:
+    c = JsimCfg()
+    c.T = int(T)
+    c.max_iter = int(config.MAX_ITER)
+    c.dt, c.dl, c.L = float(dt), float(dl), float(L)
+    c.w_perp, c.w_para = float(config.w_perp), float(config.w_para)
+    c.R[:] = [float(v) for v in config.R]
+    c.Rd[:] = [float(v) for v in config.Rd]
+    c.Q_v_yaw[:] = [float(v) for v in config.Q_v_yaw]
+    c.Qf[:] = [float(v) for v in config.Qf]
+    c.R_end[:] = [float(v) for v in config.R_END]
+    c.max_dsteer = config.max_dsteer_rad
+    c.max_accel = float(config.MAX_ACCEL)
+    c.max_decel = float(config.MAX_DECEL)
+    c.max_steer = float(config.MAX_STEER_RAD)
+    c.max_speed = float(config.MAX_SPEED)
+    c.min_speed = float(config.MIN_SPEED)
+    c.min_ref_speed = float(config.MIN_REF_SPEED)
+    c.goal_dis = float(config.GOAL_DIS)
+    c.stop_speed = float(config.STOP_SPEED)
+    return c
+
+
+def check(rc: int, ctx=None, what: str = "jsim call") -> None:
+    if rc != 0:
+        msg = load().jsim_last_error(ctx)
+        raise JsimError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,42 @@
+"""Build libjsim_mpc.so (HIP, gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "jsim_mpc.hip")
+INC = os.path.join(os.path.dirname(_HERE), "include")
+LIB = os.path.join(_HERE, "libjsim_mpc.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off",  # S1-S3 follow numpy's operation order; fma() is explicit where wanted
+               "-fno-fast-math"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libjsim_mpc.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    deps = [SRC, os.path.join(INC, "jsim_mpc.h")]
+    return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, SRC, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

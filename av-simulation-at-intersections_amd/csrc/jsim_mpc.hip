@@ -1,0 +1,1125 @@
+// jsim_mpc.hip -- MI355X (gfx950 / CDNA4) batched receding-horizon MPC step + the C-ABI of
+// include/jsim_mpc.h.  Hand-written HIP, no CUDA-compat layers.  Compile with -ffp-contract=off:
+// stages S1-S3 follow numpy's operation order (integer outputs are bit-exact); where a fused
+// multiply-add is wanted it is written as fma().
+//
+// One wavefront (64 lanes) owns one ego for the whole step:
+//   S1  reference window      nearest path point (3 smallest distances, wave arg-min), travel -> idx, gather xref
+//                             reference: main/lib/mpc.py:89-112, main/lib/trajectories.py:100-126
+//   S2  nonlinear rollout     lane t holds time step t; transcendental work lane-parallel, the three
+//                             running sums sequential (same order as the reference's python loop)
+//                             reference: main/lib/mpc.py:115-129, main/lib/simulation.py:35-47, main/bicycle/main.py:28-41
+//   S3  linearisation         A_t,B_t,C_t coefficients per lane (delta_bar == 0 => v, yaw rows are integrators)
+//                             reference: main/lib/mpc.py:61-82
+//   S4a condense + Hessian    sensitivities generated on the fly from prefix sums; H = 2 S'QS on the fp64
+//                             matrix cores (v_mfma_f64_16x16x4_f64, K = the 4 state components of one time
+//                             step), block-triangular zero tiles skipped; g, R, Rd terms on the VALU
+//                             reference: main/lib/mpc.py:141-186 (cost), :176-178,189 (dynamics eliminated)
+//   S4b exact QP solve        Goldfarb-Idnani dual active set; H -> L (Cholesky) -> J = L^-T and the working
+//                             set's R factor live in LDS (lane i owns row i); constraints are evaluated from
+//                             their structure (boxes, steer-rate differences, speed = prefix sums of accel)
+//                             reference: main/lib/mpc.py:187-199 (constraints; cvxpy->ECOS solve replaced)
+//   S5  outputs               predicted states of the linearised model, warm start, target_ind, active mask
+//                             reference: main/lib/mpc.py:200-205, 293-303
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "jsim_mpc.h"
+
+#define JSIM_VIOL_TOL 1e-10
+#define JSIM_DEP_TOL 1e-18
+#define JSIM_ACT_TOL 1e-9
+#define JSIM_FEAS_TOL 1e-8
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct KP {
+    int T, n, ld, B;
+    double dt, dl, L, w_perp, w_para;
+    double R0, R1, Rd0, Rd1, Qv, Qyaw, Qf0, Qf1, Qf2, Qf3, Re0, Re1; // Qf* already multiplied by T
+    double dmax, amax, amin, smax, vmax_plant, vmin, vref_min;
+    const double2 *pxy;
+    const double *pyaw;
+    const long long *poff;
+    const double *x0;
+    const int *path_id;
+    const int *path_len;
+    const double *speed;
+    long long *target_ind;
+    double *oa, *od, *ox, *oy, *ov, *oyaw, *xref;
+    unsigned *amask;
+    int *status;
+    int *n_iter;
+    double *dbg_xbar;
+    long long *dbg_idx;
+    double *dbg_H, *dbg_g, *dbg_lam;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes)
+// ---------------------------------------------------------------------------------------------------
+#define LDS_SYNC() __syncthreads() /* single-wave workgroup: orders LDS traffic, the barrier itself is free */
+
+__device__ __forceinline__ double rdlane(double v, int l)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uni(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// lexicographic arg-min on (v, id): smaller v, ties -> smaller id
+__device__ __forceinline__ void wargmin(double &v, int &id)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        double ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(id, o);
+        bool take = (ov < v) || (ov == v && oi < id);
+        v = take ? ov : v;
+        id = take ? oi : id;
+    }
+}
+// arg-max on (v, id): larger v, ties -> smaller id
+__device__ __forceinline__ void wargmax(double &v, int &id)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        double ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(id, o);
+        bool take = (ov > v) || (ov == v && oi < id);
+        v = take ? ov : v;
+        id = take ? oi : id;
+    }
+}
+// exclusive prefix sum over lanes
+__device__ __forceinline__ double wexscan(double v, int lane)
+{
+    double s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(s, o);
+        if (lane >= o) s += t;
+    }
+    double e = __shfl_up(s, 1);
+    return lane == 0 ? 0.0 : e;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the step kernel.  RPL = rows of the n x n factors owned by one lane (n <= 64*RPL).
+// ---------------------------------------------------------------------------------------------------
+enum { TQ_PA = 0, TQ_PB, TQ_PAP, TQ_PBP, TQ_KT, TQ_QXX, TQ_QXY, TQ_QYY, TQ_QV, TQ_QYAW, TQ_QEX, TQ_QEY,
+       TQ_QEV, TQ_QEYAW, TQ_REND, TQ_COUNT };
+
+__host__ __device__ static inline size_t jsim_lds_doubles(int T)
+{
+    const size_t n = 2 * (size_t)T, ld = n + 1, tp = (size_t)T + 2;
+    //      Jm       Rm       dvec uvec   lamv gsv    rdg ldg  actv(int)  mask    tq
+    return n * ld + n * ld + n + (n + 4) + n + 2 * n + n + n + (n + 1) / 2 + 1 + ((8 * (size_t)T + 31) / 32 + 1) / 2 + 1 +
+           TQ_COUNT * tp;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int ego = blockIdx.x;
+    if (ego >= P.B) return;
+    const int T = P.T, n = P.n, ld = P.ld, tp = T + 2;
+    const int MW = (8 * T + 31) >> 5;
+
+    double *Jm = lds;
+    double *Rm = Jm + (size_t)n * ld;
+    double *dvec = Rm + (size_t)n * ld;
+    double *uvec = dvec + n;          // n + 4
+    double *lamv = uvec + n + 4;      // n
+    double *gsv = lamv + n;           // 2n  Givens (c, s)
+    double *rdg = gsv + 2 * n;        // n   1 / R[k][k]
+    double *ldg = rdg + n;            // n   1 / L[k][k]
+    int *actv = (int *)(ldg + n);     // n ints
+    unsigned *maskw = (unsigned *)(ldg + n + (n + 1) / 2 + 1);
+    double *tq = ldg + n + (n + 1) / 2 + 1 + (MW + 1) / 2 + 1;
+
+    // ------------------------------------------------------------------ inputs (wave-uniform)
+    const int pid = P.path_id[ego];
+    const long long off = P.poff[pid];
+    const long long M = P.path_len[ego];
+    const long long s0 = P.target_ind[ego];
+    const double sx = P.x0[4 * ego + 0], sy = P.x0[4 * ego + 1], sv = P.x0[4 * ego + 2], syaw = P.x0[4 * ego + 3];
+    const double speed = P.speed[ego];
+    const double dt = P.dt;
+
+    // ------------------------------------------------------------------ S1: nearest index in direction
+    long long tind = s0;
+    int status = JSIM_OK;
+    {
+        long long len = M - s0;
+        if (len < 0) len = 0;
+        if (M < 1) {
+            status = 3;
+        } else if (len >= 3) {
+            double b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+            int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
+            const double2 *pp = P.pxy + off + s0;
+            for (int k = lane; k < (int)len; k += 64) {
+                double2 p = pp[k];
+                double dx = p.x - sx, dy = p.y - sy;
+                double d = sqrt(dx * dx + dy * dy); // numpy: sqrt(add.reduce(x*x))
+                if (d < b0) { b2 = b1; i2 = i1; b1 = b0; i1 = i0; b0 = d; i0 = k; }
+                else if (d < b1) { b2 = b1; i2 = i1; b1 = d; i1 = k; }
+                else if (d < b2) { b2 = d; i2 = k; }
+            }
+            int gi[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double dm = b0;
+                int im = i0;
+                wargmin(dm, im);
+                gi[r] = im;
+                if (i0 == im) { b0 = b1; i0 = i1; b1 = b2; i1 = i2; b2 = INFINITY; i2 = 0x7fffffff; }
+            }
+            int g0 = uni(gi[0]), g1 = uni(gi[1]), g2 = uni(gi[2]);
+            int d12 = g1 - g2; d12 = d12 < 0 ? -d12 : d12;
+            int d01 = g0 - g1; d01 = d01 < 0 ? -d01 : d01;
+            if (d12 == 2) tind = g0 + s0;
+            else if (d01 == 1) tind = (g0 > g1 ? g0 : g1) + s0;
+            else status = JSIM_NEAREST_ANOMALY;
+        } else if (len == 2) {
+            tind = s0 + 1;
+        }
+    }
+    if (status != JSIM_OK) { // reference raises: nothing is updated
+        if (lane == 0) {
+            P.status[ego] = status;
+            if (P.n_iter) P.n_iter[ego] = 0;
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ S1: travel -> idx -> xref
+    const int tl_idx = lane < T ? lane : T; // lanes > T mirror lane T (keeps loads in range)
+    double xr, yr, yawr;
+    bool rend;
+    long long ik;
+    {
+        double vref = (P.vref_min > sv) ? P.vref_min : sv; // python max(state.v, 10/3.6)
+        double cstep = fabs(vref) * dt;
+        double trav = cstep;
+        for (int j = 1; j <= T; ++j)
+            if (j <= tl_idx) trav = trav + cstep; // np.cumsum: sequential
+        ik = (long long)rint(trav / P.dl) + tind;
+        if (ik > M - 1) ik = M - 1;
+        double2 pr = P.pxy[off + ik];
+        xr = pr.x; yr = pr.y; yawr = P.pyaw[off + ik];
+        rend = (ik == M - 1);
+    }
+
+    // infeasible constant rows x[2,0] <= speed, x[2,0] >= MIN_SPEED (ECOS feasibility tolerance)
+    if (speed - sv < -JSIM_FEAS_TOL || sv - P.vmin < -JSIM_FEAS_TOL) status = JSIM_INFEASIBLE;
+
+    // ------------------------------------------------------------------ S2: rollout of the warm start
+    const bool tl = lane < T;
+    double wa_t = tl ? P.oa[(size_t)ego * T + lane] : 0.0;
+    double wd_t = tl ? P.od[(size_t)ego * T + lane] : 0.0;
+    double bx = sx, by = sy, bv = sv, bth = syaw, sn, cs;
+    {
+        double dc = (P.smax < wd_t) ? P.smax : wd_t;   // min(delta, MAX_STEER)
+        dc = (-P.smax > dc) ? -P.smax : dc;            // max(.., -MAX_STEER)
+        double tan_t = tan(dc);
+        double vcur = sv;
+        for (int j = 0; j < T; ++j) {
+            double aj = rdlane(wa_t, j);
+            double vn = vcur + aj * dt;
+            vn = (P.vmax_plant < vn) ? P.vmax_plant : vn;
+            vn = (P.vmin > vn) ? P.vmin : vn;
+            vcur = vn;
+            if (lane == j + 1) bv = vn;
+        }
+        double w = ((bv / P.L) * tan_t) * dt;
+        double thcur = syaw;
+        for (int j = 0; j < T; ++j) {
+            thcur = thcur + rdlane(w, j);
+            if (lane == j + 1) bth = thcur;
+        }
+        sincos(bth, &sn, &cs);
+        double ix = (bv * cs) * dt, iy = (bv * sn) * dt;
+        double xcur = sx, ycur = sy;
+        for (int j = 0; j < T; ++j) {
+            xcur = xcur + rdlane(ix, j);
+            ycur = ycur + rdlane(iy, j);
+            if (lane == j + 1) { bx = xcur; by = ycur; }
+        }
+    }
+    if (P.dbg_xbar && lane <= T) {
+        double *xb = P.dbg_xbar + (size_t)ego * 4 * (T + 1);
+        xb[0 * (T + 1) + lane] = bx; xb[1 * (T + 1) + lane] = by;
+        xb[2 * (T + 1) + lane] = bv; xb[3 * (T + 1) + lane] = bth;
+    }
+    if (P.dbg_idx && lane <= T) P.dbg_idx[(size_t)ego * (T + 1) + lane] = ik;
+    if (P.xref && lane <= T) {
+        double *xf = P.xref + (size_t)ego * 4 * (T + 1);
+        xf[0 * (T + 1) + lane] = xr; xf[1 * (T + 1) + lane] = yr;
+        xf[2 * (T + 1) + lane] = 0.0; xf[3 * (T + 1) + lane] = yawr;
+    }
+    if (status == JSIM_INFEASIBLE) {
+        // reference: solver reports infeasible -> None outputs; target_ind/xref are still stored (mpc.py:293)
+        if (tl) { P.oa[(size_t)ego * T + lane] = 0.0; P.od[(size_t)ego * T + lane] = 0.0; }
+        if (P.amask && lane < MW) P.amask[(size_t)ego * MW + lane] = 0u;
+        if (lane == 0) {
+            P.status[ego] = status;
+            P.target_ind[ego] = tind;
+            if (P.n_iter) P.n_iter[ego] = 0;
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ S3: linearisation coefficients (lane t < T)
+    double al = 0, be = 0, alp = 0, bep = 0, ccx = 0, ccy = 0, kt = 0;
+    if (tl) {
+        al = dt * cs;                 // A[0,2]
+        be = (-dt * bv) * sn;         // A[0,3]
+        alp = dt * sn;                // A[1,2]
+        bep = (dt * bv) * cs;         // A[1,3]
+        ccx = ((dt * bv) * sn) * bth; // C[0]
+        ccy = ((-dt * bv) * cs) * bth; // C[1]
+        kt = (dt * bv) / P.L;         // B[3,1] with delta_bar = 0
+    }
+    {
+        // exclusive prefix sums over time: x_t = x0 + sum_{r<t}(al_r v_r + be_r yaw_r + ccx_r)
+        double PA = wexscan(al, lane), PB = wexscan(be, lane), PAP = wexscan(alp, lane), PBP = wexscan(bep, lane);
+        double FX = sx + wexscan(fma(al, sv, fma(be, syaw, ccx)), lane);
+        double FY = sy + wexscan(fma(alp, sv, fma(bep, syaw, ccy)), lane);
+        double Qxx = 0, Qxy = 0, Qyy = 0, qv = 0, qyaw = 0;
+        if (lane >= 1 && lane <= T) {
+            if (!rend) {
+                double a1 = yawr + 0.5 * M_PI;
+                double c1 = cos(a1), s1 = sin(a1), c2 = cos(yawr), s2 = sin(yawr);
+                Qxx = (c1 * c1) * P.w_perp + (c2 * c2) * P.w_para;
+                Qxy = (c1 * s1) * P.w_perp + (c2 * s2) * P.w_para;
+                Qyy = (s1 * s1) * P.w_perp + (s2 * s2) * P.w_para;
+                qv = P.Qv; qyaw = P.Qyaw;
+            } else {
+                Qxx = P.Qf0; Qyy = P.Qf1; qv = P.Qf2; qyaw = P.Qf3;
+            }
+        }
+        double ex = FX - xr, ey = FY - yr, ev = sv, eyaw = syaw - yawr;
+        if (lane <= T + 1) {
+            const int t = lane;
+            bool in = lane <= T;
+            tq[TQ_PA * tp + t] = PA; tq[TQ_PB * tp + t] = PB; tq[TQ_PAP * tp + t] = PAP; tq[TQ_PBP * tp + t] = PBP;
+            tq[TQ_KT * tp + t] = kt;
+            tq[TQ_QXX * tp + t] = in ? Qxx : 0; tq[TQ_QXY * tp + t] = in ? Qxy : 0; tq[TQ_QYY * tp + t] = in ? Qyy : 0;
+            tq[TQ_QV * tp + t] = in ? qv : 0; tq[TQ_QYAW * tp + t] = in ? qyaw : 0;
+            tq[TQ_QEX * tp + t] = in ? fma(Qxx, ex, Qxy * ey) : 0;
+            tq[TQ_QEY * tp + t] = in ? fma(Qxy, ex, Qyy * ey) : 0;
+            tq[TQ_QEV * tp + t] = in ? qv * ev : 0;
+            tq[TQ_QEYAW * tp + t] = in ? qyaw * eyaw : 0;
+            tq[TQ_REND * tp + t] = (in && rend) ? 1.0 : 0.0;
+        }
+    }
+    LDS_SYNC();
+
+    // ------------------------------------------------------------------ S4a: H = 2 S'QS on the fp64 matrix cores
+    // v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+    // D[row = (lane>>4) + 4*reg][col = lane&15].  k = state component of time step t; tile columns = 8 time steps.
+    {
+        const int ntile = (n + 15) >> 4;
+        const int kk = lane >> 4, cc = lane & 15;
+        for (int ti = 0; ti < ntile; ++ti) {
+            const int ca = 16 * ti + cc;
+            const bool va = ca < n;
+            const int sa = va ? (ca >> 1) : (T - 1);
+            const bool isda = ca & 1;
+            const double kta = tq[TQ_KT * tp + sa];
+            const double coefa = va ? (isda ? kta : dt) : 0.0;
+            const double pax = isda ? tq[TQ_PB * tp + sa + 1] : tq[TQ_PA * tp + sa + 1];
+            const double pay = isda ? tq[TQ_PBP * tp + sa + 1] : tq[TQ_PAP * tp + sa + 1];
+            const double c23a = !va ? 0.0 : (kk == 2 ? (isda ? 0.0 : dt) : (kk == 3 ? (isda ? kta : 0.0) : 0.0));
+            const double *ptxa = isda ? &tq[TQ_PB * tp] : &tq[TQ_PA * tp];
+            const double *ptya = isda ? &tq[TQ_PBP * tp] : &tq[TQ_PAP * tp];
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int cb = 16 * tj + cc;
+                const bool vb = cb < n;
+                const int sb = vb ? (cb >> 1) : (T - 1);
+                const bool isdb = cb & 1;
+                const double ktb = tq[TQ_KT * tp + sb];
+                const double coefb = vb ? (isdb ? ktb : dt) : 0.0;
+                const double pbx = isdb ? tq[TQ_PB * tp + sb + 1] : tq[TQ_PA * tp + sb + 1];
+                const double pby = isdb ? tq[TQ_PBP * tp + sb + 1] : tq[TQ_PAP * tp + sb + 1];
+                const double c23b = !vb ? 0.0 : (kk == 2 ? (isdb ? 0.0 : dt) : (kk == 3 ? (isdb ? ktb : 0.0) : 0.0));
+                const double *ptxb = isdb ? &tq[TQ_PB * tp] : &tq[TQ_PA * tp];
+                const double *ptyb = isdb ? &tq[TQ_PBP * tp] : &tq[TQ_PAP * tp];
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                for (int t = 8 * ti + 1; t <= T; ++t) { // S_t has no entry in tile ti before t = 8*ti + 1
+                    double aval;
+                    {
+                        const bool v1 = t > sa, v2 = t >= sa + 2;
+                        double S0 = v2 ? coefa * (ptxa[t] - pax) : 0.0;
+                        double S1 = v2 ? coefa * (ptya[t] - pay) : 0.0;
+                        double S23 = v1 ? c23a : 0.0;
+                        aval = kk == 0 ? S0 : (kk == 1 ? S1 : S23);
+                    }
+                    double bval;
+                    {
+                        const bool v1 = t > sb, v2 = t >= sb + 2;
+                        double S0 = v2 ? coefb * (ptxb[t] - pbx) : 0.0;
+                        double S1 = v2 ? coefb * (ptyb[t] - pby) : 0.0;
+                        double S23 = v1 ? c23b : 0.0;
+                        double qxx = tq[TQ_QXX * tp + t], qxy = tq[TQ_QXY * tp + t], qyy = tq[TQ_QYY * tp + t];
+                        double q23 = kk == 2 ? tq[TQ_QV * tp + t] : tq[TQ_QYAW * tp + t];
+                        bval = kk == 0 ? fma(qxx, S0, qxy * S1) : (kk == 1 ? fma(qxy, S0, qyy * S1) : q23 * S23);
+                    }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + kk + 4 * r, col = 16 * tj + cc;
+                    if (row < n && col < n) {
+                        double hv = 2.0 * acc[r];
+                        Rm[row * ld + col] = hv;
+                        if (ti != tj) Rm[col * ld + row] = hv;
+                    }
+                }
+            }
+        }
+    }
+    LDS_SYNC();
+
+    // input cost R / R_end (mpc.py:180-183), input-difference cost Rd (mpc.py:186), and g = 2 S'Q(f - xref)
+    double gmax;
+    {
+        double gl = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int i = lane + 64 * rr;
+            if (i < n) {
+                const int t = i >> 1, c = i & 1;
+                const double Rt = (tq[TQ_REND * tp + t] != 0.0) ? (c ? P.Re1 : P.Re0) : (c ? P.R1 : P.R0);
+                const double rdc = 2.0 * (c ? P.Rd1 : P.Rd0);
+                const int nd = (T >= 2) ? ((t == 0 || t == T - 1) ? 1 : 2) : 0;
+                Rm[i * ld + i] += 2.0 * Rt + nd * rdc;
+                if (t + 1 < T) Rm[i * ld + i + 2] -= rdc;
+                if (t >= 1) Rm[i * ld + i - 2] -= rdc;
+                // g_i
+                const bool isd = c;
+                const double ks = tq[TQ_KT * tp + t];
+                const double coef = isd ? ks : dt;
+                const double px = isd ? tq[TQ_PB * tp + t + 1] : tq[TQ_PA * tp + t + 1];
+                const double py = isd ? tq[TQ_PBP * tp + t + 1] : tq[TQ_PAP * tp + t + 1];
+                const double *ptx = isd ? &tq[TQ_PB * tp] : &tq[TQ_PA * tp];
+                const double *pty = isd ? &tq[TQ_PBP * tp] : &tq[TQ_PAP * tp];
+                const double *q23 = isd ? &tq[TQ_QEYAW * tp] : &tq[TQ_QEV * tp];
+                double acc = 0.0;
+                for (int tt = t + 1; tt <= T; ++tt) {
+                    acc = fma(coef, q23[tt], acc);
+                    if (tt >= t + 2) {
+                        acc = fma(coef * (ptx[tt] - px), tq[TQ_QEX * tp + tt], acc);
+                        acc = fma(coef * (pty[tt] - py), tq[TQ_QEY * tp + tt], acc);
+                    }
+                }
+                const double gi = 2.0 * acc;
+                dvec[i] = gi;
+                gl = fmax(gl, fabs(gi));
+                if (P.dbg_g) P.dbg_g[(size_t)ego * n + i] = gi;
+            }
+        }
+        gmax = uni(wmax(gl));
+    }
+    LDS_SYNC();
+    if (P.dbg_H) {
+        double *Hd = P.dbg_H + (size_t)ego * n * n;
+        for (int e = lane; e < n * n; e += 64) {
+            int r = e / n, c = e - r * n;
+            Hd[e] = (c <= r) ? Rm[r * ld + c] : Rm[c * ld + r];
+        }
+    }
+
+    // ------------------------------------------------------------------ S4b: Cholesky H = L L' (in place, lower), lane = row
+    for (int k = 0; k < n; ++k) {
+        double s[RPL];
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int i = lane + 64 * rr;
+            s[rr] = (i >= k && i < n) ? Rm[i * ld + k] : 0.0;
+        }
+        for (int j = 0; j < k; ++j) {
+            const double lkj = Rm[k * ld + j];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int i = lane + 64 * rr;
+                if (i >= k && i < n) s[rr] = fma(-Rm[i * ld + j], lkj, s[rr]);
+            }
+        }
+        double dkk = (RPL == 1 || k < 64) ? rdlane(s[0], k & 63) : rdlane(s[RPL - 1], k & 63);
+        if (!(dkk > 0.0)) dkk = 1e-300; // H is SPD by construction (>= 2 min(R) I)
+        const double lkk = sqrt(dkk);
+        const double inv = 1.0 / lkk;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int i = lane + 64 * rr;
+            if (i == k) { Rm[k * ld + k] = lkk; ldg[k] = inv; }
+            else if (i > k && i < n) Rm[i * ld + k] = s[rr] * inv;
+        }
+        LDS_SYNC();
+    }
+
+    // ------------------------------------------------------------------ J = L^-T : lane r owns row r, J[r][i] = (L^-1)[i][r]
+    for (int i = 0; i < n; ++i) {
+        double s[RPL];
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) s[rr] = (lane + 64 * rr == i) ? 1.0 : 0.0;
+        for (int j = 0; j < i; ++j) {
+            const double lij = Rm[i * ld + j];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int r = lane + 64 * rr;
+                if (r <= j && r < n) s[rr] = fma(-lij, Jm[r * ld + j], s[rr]);
+            }
+        }
+        const double inv = ldg[i];
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int r = lane + 64 * rr;
+            if (r < n) Jm[r * ld + i] = (r <= i) ? s[rr] * inv : 0.0;
+        }
+    }
+    LDS_SYNC();
+
+    // ------------------------------------------------------------------ unconstrained optimum u = -J J' g
+    double u[RPL];
+    {
+        double tc[RPL];
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) tc[rr] = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double gi = dvec[i];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int j = lane + 64 * rr;
+                if (j < n) tc[rr] = fma(Jm[i * ld + j], gi, tc[rr]);
+            }
+        }
+        LDS_SYNC();
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int j = lane + 64 * rr;
+            if (j < n) dvec[j] = tc[rr];
+        }
+        LDS_SYNC();
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) u[rr] = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double tj = dvec[j];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int i = lane + 64 * rr;
+                if (i < n) u[rr] = fma(Jm[i * ld + j], tj, u[rr]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int i = lane + 64 * rr;
+            u[rr] = -u[rr];
+            if (i < n) uvec[i] = u[rr];
+        }
+        if (lane < 4) uvec[n + lane] = 0.0;
+        if (lane < MW) maskw[lane] = 0u;
+    }
+    LDS_SYNC();
+
+    // ------------------------------------------------------------------ Goldfarb-Idnani dual active-set iterations
+    int q = 0, iters = 0;
+    const int max_iters = 50 * n + 100;
+    unsigned abits = 0; // lane t: which of the 8 rows of time step t are in the working set
+    for (;;) {
+        // ---- step 1: most violated row (ties -> lowest canonical index)
+        int p;
+        double violp;
+        {
+            const int t = lane;
+            double a = 0.0, dl_ = 0.0, dnext = 0.0;
+            if (t < T) { double2 ad = *(const double2 *)&uvec[2 * t]; a = ad.x; dl_ = ad.y; dnext = uvec[2 * t + 3]; }
+            const double vt = sv + dt * wexscan(a, lane);
+            double best = 0.0;
+            int bid = 0x7fffffff;
+#define CONSIDER(valid, bit, viol_expr, habs, id_expr)                                   \
+    if ((valid) && !(abits & (1u << (bit)))) {                                           \
+        const double vv = (viol_expr);                                                   \
+        const int id_ = (id_expr);                                                       \
+        if (vv > JSIM_VIOL_TOL * (1.0 + (habs)) && (vv > best || (vv == best && id_ < bid))) { best = vv; bid = id_; } \
+    }
+            CONSIDER(t + 1 < T, 0, (dnext - dl_) - P.dmax, P.dmax, 2 * t)
+            CONSIDER(t + 1 < T, 1, (dl_ - dnext) - P.dmax, P.dmax, 2 * t + 1)
+            CONSIDER(t >= 1 && t <= T, 2, vt - speed, fabs(speed - sv), 2 * T - 2 + t)
+            CONSIDER(t >= 1 && t <= T, 3, P.vmin - vt, fabs(sv - P.vmin), 3 * T - 1 + t)
+            CONSIDER(t < T, 4, a - P.amax, fabs(P.amax), 4 * T + t)
+            CONSIDER(t < T, 5, P.amin - a, fabs(P.amin), 5 * T + t)
+            CONSIDER(t < T, 6, dl_ - P.smax, P.smax, 6 * T + 2 * t)
+            CONSIDER(t < T, 7, -dl_ - P.smax, P.smax, 6 * T + 2 * t + 1)
+#undef CONSIDER
+            wargmax(best, bid);
+            p = uni(bid);
+            violp = uni(best);
+        }
+        if (p == 0x7fffffff) break; // optimal
+
+        // decode row p
+        int kind, tp_, neg = 0;
+        if (p < 2 * T - 2) { kind = 0; tp_ = p >> 1; neg = p & 1; }
+        else if (p < 3 * T - 1) { kind = 1; tp_ = p - (2 * T - 2); }
+        else if (p < 4 * T) { kind = 2; tp_ = p - (3 * T - 1); }
+        else if (p < 5 * T) { kind = 3; tp_ = p - 4 * T; }
+        else if (p < 6 * T) { kind = 4; tp_ = p - 5 * T; }
+        else { kind = 5; tp_ = (p - 6 * T) >> 1; neg = (p - 6 * T) & 1; }
+        const unsigned pbit = kind == 0 ? (neg ? 2u : 1u) : kind == 1 ? 4u : kind == 2 ? 8u : kind == 3 ? 16u
+                              : kind == 4 ? 32u : (neg ? 128u : 64u);
+        double lplus = 0.0;
+        bool failed = false;
+
+        for (;;) { // ---- step 2
+            if (++iters > max_iters) { failed = true; break; }
+            // d = J' n+, n+ = -G_p'   (lane j = column j of J)
+            double d[RPL];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int j = lane + 64 * rr;
+                double dj = 0.0;
+                if (j < n) {
+                    if (kind == 0) {
+                        double e = Jm[(2 * tp_ + 1) * ld + j] - Jm[(2 * tp_ + 3) * ld + j]; // -(J[d_{t+1}] - J[d_t])
+                        dj = neg ? -e : e;
+                    } else if (kind == 1 || kind == 2) {
+                        double s = 0.0;
+                        for (int ss = 0; ss < tp_; ++ss) s += Jm[(2 * ss) * ld + j];
+                        dj = (kind == 1) ? -dt * s : dt * s;
+                    } else if (kind == 3) dj = -Jm[(2 * tp_) * ld + j];
+                    else if (kind == 4) dj = Jm[(2 * tp_) * ld + j];
+                    else dj = neg ? Jm[(2 * tp_ + 1) * ld + j] : -Jm[(2 * tp_ + 1) * ld + j];
+                    dvec[j] = dj;
+                }
+                d[rr] = dj;
+            }
+            double dd_l = 0.0, zn_l = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int j = lane + 64 * rr;
+                const double sq = d[rr] * d[rr];
+                dd_l += sq;
+                if (j >= q) zn_l += sq;
+            }
+            const double dd = uni(wsum(dd_l)), zn = uni(wsum(zn_l));
+            LDS_SYNC();
+            // z = J2 d2 (lane i = row i)
+            double z[RPL];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) z[rr] = 0.0;
+            for (int j = q; j < n; ++j) {
+                const double dj = dvec[j];
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int i = lane + 64 * rr;
+                    if (i < n) z[rr] = fma(Jm[i * ld + j], dj, z[rr]);
+                }
+            }
+            // r = R^-1 d1 (back substitution; lane k = row k of R)
+            double r[RPL];
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) r[rr] = d[rr];
+            for (int j = q - 1; j >= 0; --j) {
+                const double rj = ((RPL == 1 || j < 64) ? rdlane(r[0], j & 63) : rdlane(r[RPL - 1], j & 63)) * rdg[j];
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int i = lane + 64 * rr;
+                    if (i == j) r[rr] = rj;
+                    else if (i < j) r[rr] = fma(-Rm[i * ld + j], rj, r[rr]);
+                }
+            }
+            // dual ratio test
+            int l;
+            double t1;
+            {
+                double bt = INFINITY;
+                int bk = 0x7fffffff;
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int k = lane + 64 * rr;
+                    if (k < q && r[rr] > 0.0) {
+                        double tk = lamv[k] / r[rr];
+                        if (tk < bt) { bt = tk; bk = k; }
+                    }
+                }
+                wargmin(bt, bk);
+                t1 = uni(bt);
+                l = uni(bk);
+            }
+            const bool dependent = !(zn > JSIM_DEP_TOL * dd);
+            double t2 = dependent ? INFINITY : violp / zn;
+            if (t2 < 0.0) t2 = 0.0;
+            if (isinf(t1) && isinf(t2)) { failed = true; break; }
+            const bool full = (t2 <= t1);
+            const double tstep = full ? t2 : t1;
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int i = lane + 64 * rr;
+                if (!dependent && i < n) { u[rr] = fma(tstep, z[rr], u[rr]); uvec[i] = u[rr]; }
+                if (i < q) {
+                    double lk = fma(-tstep, r[rr], lamv[i]);
+                    lamv[i] = lk < 0.0 ? 0.0 : lk;
+                }
+            }
+            lplus += tstep;
+
+            if (full) {
+                // add p: one Householder reflection on d2; J2 <- J2 P ; new R column [d1; rho]
+                const double nrm = sqrt(zn);
+                const double dq = (RPL == 1 || q < 64) ? rdlane(d[0], q & 63) : rdlane(d[RPL - 1], q & 63);
+                const double sg = dq >= 0.0 ? 1.0 : -1.0;
+                const double rho = -sg * nrm;
+                const double v0 = dq + sg * nrm;
+                const double beta = 1.0 / (nrm * (nrm + fabs(dq)));
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int i = lane + 64 * rr;
+                    if (i < n) {
+                        const double w = beta * fma(sg * nrm, Jm[i * ld + q], z[rr]);
+                        Jm[i * ld + q] = fma(-w, v0, Jm[i * ld + q]);
+                        for (int j = q + 1; j < n; ++j) Jm[i * ld + j] = fma(-w, dvec[j], Jm[i * ld + j]);
+                    }
+                    if (i < q) Rm[i * ld + q] = d[rr];
+                    if (i == q) { Rm[q * ld + q] = rho; rdg[q] = 1.0 / rho; actv[q] = p; lamv[q] = lplus; }
+                }
+                if (lane == tp_) abits |= pbit;
+                ++q;
+                LDS_SYNC();
+                break;
+            }
+            // partial step: drop working-set position l
+            {
+                const int pdrop = actv[l];
+                // Givens sweep on R (lane k = column k), coefficients kept for the J pass
+                for (int j = l; j + 1 < q; ++j) {
+                    const double a = Rm[j * ld + j + 1], b = Rm[(j + 1) * ld + j + 1];
+                    const double hh = sqrt(a * a + b * b);
+                    double c = 1.0, s = 0.0;
+                    if (hh > 0.0) { c = a / hh; s = b / hh; }
+#pragma unroll
+                    for (int rr = 0; rr < RPL; ++rr) {
+                        const int k = lane + 64 * rr;
+                        if (k >= j + 1 && k < q) {
+                            const double x1 = Rm[j * ld + k], x2 = Rm[(j + 1) * ld + k];
+                            Rm[j * ld + k] = fma(c, x1, s * x2);
+                            Rm[(j + 1) * ld + k] = fma(-s, x1, c * x2);
+                        }
+                    }
+                    if (lane == 0) { gsv[2 * j] = c; gsv[2 * j + 1] = s; }
+                    LDS_SYNC();
+                }
+                // same rotations on the columns of J (lane i = row i, carried column)
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int i = lane + 64 * rr;
+                    if (i < n) {
+                        double carry = Jm[i * ld + l];
+                        for (int j = l; j + 1 < q; ++j) {
+                            const double nx = Jm[i * ld + j + 1];
+                            const double c = gsv[2 * j], s = gsv[2 * j + 1];
+                            Jm[i * ld + j] = fma(c, carry, s * nx);
+                            carry = fma(-s, carry, c * nx);
+                        }
+                        Jm[i * ld + q - 1] = carry;
+                    }
+                }
+                // shift R's columns, the working-set list and the multipliers left
+                int an[RPL];
+                double ln[RPL];
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int k = lane + 64 * rr;
+                    if (k < q) {
+                        for (int j = (k > l ? k : l); j + 1 < q; ++j) Rm[k * ld + j] = Rm[k * ld + j + 1];
+                    }
+                    an[rr] = (k >= l && k + 1 < q) ? actv[k + 1] : 0;
+                    ln[rr] = (k >= l && k + 1 < q) ? lamv[k + 1] : 0.0;
+                }
+                LDS_SYNC();
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) {
+                    const int k = lane + 64 * rr;
+                    if (k >= l && k + 1 < q) { actv[k] = an[rr]; lamv[k] = ln[rr]; rdg[k] = 1.0 / Rm[k * ld + k]; }
+                }
+                --q;
+                // clear the dropped row's working-set bit on its time lane
+                {
+                    int dk, dt_, dneg = 0;
+                    if (pdrop < 2 * T - 2) { dk = 0; dt_ = pdrop >> 1; dneg = pdrop & 1; }
+                    else if (pdrop < 3 * T - 1) { dk = 1; dt_ = pdrop - (2 * T - 2); }
+                    else if (pdrop < 4 * T) { dk = 2; dt_ = pdrop - (3 * T - 1); }
+                    else if (pdrop < 5 * T) { dk = 3; dt_ = pdrop - 4 * T; }
+                    else if (pdrop < 6 * T) { dk = 4; dt_ = pdrop - 5 * T; }
+                    else { dk = 5; dt_ = (pdrop - 6 * T) >> 1; dneg = (pdrop - 6 * T) & 1; }
+                    const unsigned dbit = dk == 0 ? (dneg ? 2u : 1u) : dk == 1 ? 4u : dk == 2 ? 8u : dk == 3 ? 16u
+                                          : dk == 4 ? 32u : (dneg ? 128u : 64u);
+                    if (lane == dt_) abits &= ~dbit;
+                }
+                LDS_SYNC();
+                // violation of p at the new point
+                if (kind == 0) {
+                    double e = uvec[2 * tp_ + 3] - uvec[2 * tp_ + 1];
+                    violp = (neg ? -e : e) - P.dmax;
+                } else if (kind == 1 || kind == 2) {
+                    double a = (lane < tp_) ? uvec[2 * lane] : 0.0;
+                    double vt = sv + dt * uni(wsum(a));
+                    violp = (kind == 1) ? vt - speed : P.vmin - vt;
+                } else if (kind == 3) violp = uvec[2 * tp_] - P.amax;
+                else if (kind == 4) violp = P.amin - uvec[2 * tp_];
+                else violp = (neg ? -uvec[2 * tp_ + 1] : uvec[2 * tp_ + 1]) - P.smax;
+            }
+        }
+        if (failed) { status = JSIM_INFEASIBLE; break; }
+    }
+
+    // ------------------------------------------------------------------ S5: outputs
+    if (status != JSIM_OK) {
+        if (tl) { P.oa[(size_t)ego * T + lane] = 0.0; P.od[(size_t)ego * T + lane] = 0.0; }
+        if (P.amask && lane < MW) P.amask[(size_t)ego * MW + lane] = 0u;
+        if (lane == 0) {
+            P.status[ego] = status;
+            P.target_ind[ego] = tind;
+            if (P.n_iter) P.n_iter[ego] = iters;
+        }
+        return;
+    }
+    {
+        const double thr = JSIM_ACT_TOL * fmax(1.0, gmax);
+        if (P.dbg_lam) {
+            for (int e = lane; e < 8 * T; e += 64) P.dbg_lam[(size_t)ego * 8 * T + e] = 0.0;
+            LDS_SYNC(); // drains the zero fill (vmcnt) before other lanes store multipliers to the same words
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int k = lane + 64 * rr;
+            if (k < q) {
+                const double lk = lamv[k];
+                const int id = actv[k];
+                if (lk > thr) atomicOr(&maskw[id >> 5], 1u << (id & 31));
+                if (P.dbg_lam) P.dbg_lam[(size_t)ego * 8 * T + id] = lk;
+            }
+        }
+        LDS_SYNC();
+        if (P.amask && lane < MW) P.amask[(size_t)ego * MW + lane] = maskw[lane];
+    }
+    {
+        double a = 0.0, dl_ = 0.0;
+        if (tl) { double2 ad = *(const double2 *)&uvec[2 * lane]; a = ad.x; dl_ = ad.y; }
+        // predicted states of the linearised model at u* (= the cvxpy x variable)
+        const double vt = sv + dt * wexscan(a, lane);
+        const double yt = syaw + wexscan(kt * dl_, lane);
+        const double xt = sx + wexscan(fma(al, vt, fma(be, yt, ccx)), lane);
+        const double yy = sy + wexscan(fma(alp, vt, fma(bep, yt, ccy)), lane);
+        if (tl) { P.oa[(size_t)ego * T + lane] = a; P.od[(size_t)ego * T + lane] = dl_; }
+        if (lane <= T) {
+            const size_t o = (size_t)ego * (T + 1) + lane;
+            if (P.ox) P.ox[o] = xt;
+            if (P.oy) P.oy[o] = yy;
+            if (P.ov) P.ov[o] = vt;
+            if (P.oyaw) P.oyaw[o] = yt;
+        }
+    }
+    if (lane == 0) {
+        P.status[ego] = JSIM_OK;
+        P.target_ind[ego] = tind;
+        if (P.n_iter) P.n_iter[ego] = iters;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plant update for the per-vehicle loop (Simulation.step, main/lib/simulation.py:35-47) and the
+// controller's (di, ai) selection with the failure path (main/lib/mpc.py:298-303)
+// ---------------------------------------------------------------------------------------------------
+struct PlantP {
+    int B, T;
+    double dt, L, smax, vmax, vmin, max_decel;
+};
+
+__global__ __launch_bounds__(256) void plant_step_kernel(PlantP P, double *x0, const double *oa, const double *od,
+                                                         const int *status, double *di_ai)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    double di = di_ai[2 * b], ai;
+    if (status[b] == JSIM_OK) { di = od[(size_t)b * P.T]; ai = oa[(size_t)b * P.T]; }
+    else ai = P.max_decel;
+    di_ai[2 * b] = di;
+    di_ai[2 * b + 1] = ai;
+    double x = x0[4 * b], y = x0[4 * b + 1], v = x0[4 * b + 2], th = x0[4 * b + 3];
+    double dc = (P.smax < di) ? P.smax : di;
+    dc = (-P.smax > dc) ? -P.smax : dc;
+    const double xd = v * cos(th), yd = v * sin(th), thd = (v / P.L) * tan(dc);
+    x += xd * P.dt; y += yd * P.dt; th += thd * P.dt;
+    v += ai * P.dt;
+    v = (P.vmax < v) ? P.vmax : v;
+    v = (P.vmin > v) ? P.vmin : v;
+    x0[4 * b] = x; x0[4 * b + 1] = y; x0[4 * b + 2] = v; x0[4 * b + 3] = th;
+}
+
+struct GoalP {
+    int B, T;
+    double goal_dis, stop_speed;
+    const double2 *pxy;
+    const double *pyaw;
+    const long long *poff;
+};
+
+// MPC.get_current_xref_deviation (main/lib/mpc.py:305-312) and MPC.is_goal (:314-330)
+__global__ __launch_bounds__(256) void deviation_goal_kernel(GoalP P, const double *x0, const int *path_id,
+                                                             const int *path_len, const long long *target_ind,
+                                                             const double *ox, const double *oy, double *deviation,
+                                                             int *is_goal)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const long long off = P.poff[path_id[b]];
+    const long long full = P.poff[path_id[b] + 1] - off;
+    const long long ti = target_ind[b];
+    if (deviation) {
+        const double2 rp = P.pxy[off + ti];
+        const double yp = P.pyaw[off + ti] + M_PI / 2;
+        const double dx = rp.x - ox[(size_t)b * (P.T + 1)], dy = rp.y - oy[(size_t)b * (P.T + 1)];
+        const double a = cos(yp) * dx, c = sin(yp) * dy;
+        deviation[b] = sqrt(a * a + c * c);
+    }
+    if (is_goal) {
+        const double2 g = P.pxy[off + full - 1]; // goal = last point of the path given to MPC.__init__
+        const double d = hypot(x0[4 * b] - g.x, x0[4 * b + 1] - g.y);
+        bool isgoal = d <= P.goal_dis;
+        long long df = ti - (long long)path_len[b];
+        if ((df < 0 ? -df : df) >= 5) isgoal = false;
+        const bool isstop = fabs(x0[4 * b + 2]) <= P.stop_speed;
+        is_goal[b] = (isgoal && isstop) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------
+struct jsim_ctx {
+    jsim_cfg cfg;
+    int device;
+    double2 *d_pxy;
+    double *d_pyaw;
+    long long *d_poff;
+    int n_paths;
+    long long n_points;
+    char err[512];
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(jsim_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof(g_err), "%s", buf);
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", buf);
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                                     \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) return fail(ctx, -5, "%s failed: %s", #call, hipGetErrorString(e_));             \
+    } while (0)
+
+extern "C" int jsim_abi_version(void) { return JSIM_ABI_VERSION; }
+
+extern "C" const char *jsim_last_error(const jsim_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, -22, "jsim_mpc_create: null argument");
+    if (cfg->T < 1 || cfg->T > JSIM_MAX_T) return fail(nullptr, -22, "jsim_mpc_create: T=%d outside [1, %d]", cfg->T, JSIM_MAX_T);
+    if (cfg->max_iter != 1) return fail(nullptr, -22, "jsim_mpc_create: MAX_ITER=%d unsupported (stock value 1 only)", cfg->max_iter);
+    if (!(cfg->dt > 0) || !(cfg->dl > 0) || !(cfg->L > 0)) return fail(nullptr, -22, "jsim_mpc_create: dt, dl, L must be positive");
+    if (!(cfg->R[0] > 0) || !(cfg->R[1] > 0) || !(cfg->R_end[0] > 0) || !(cfg->R_end[1] > 0))
+        return fail(nullptr, -22, "jsim_mpc_create: R / R_end must be positive (strict convexity)");
+    int ndev = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(nullptr, -19, "jsim_mpc_create: no HIP device");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, -22, "jsim_mpc_create: device %d of %d", device_id, ndev);
+    jsim_ctx *c = new (std::nothrow) jsim_ctx();
+    if (!c) return fail(nullptr, -12, "jsim_mpc_create: out of memory");
+    memset(c, 0, sizeof(*c));
+    c->cfg = *cfg;
+    c->device = device_id;
+    *out = c;
+    return 0;
+}
+
+static void free_paths(jsim_ctx *c)
+{
+    if (c->d_pxy) (void)hipFree(c->d_pxy);
+    if (c->d_pyaw) (void)hipFree(c->d_pyaw);
+    if (c->d_poff) (void)hipFree(c->d_poff);
+    c->d_pxy = nullptr; c->d_pyaw = nullptr; c->d_poff = nullptr;
+    c->n_paths = 0; c->n_points = 0;
+}
+
+extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_paths(ctx);
+    delete ctx;
+}
+
+extern "C" int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double *cy, const double *cyaw,
+                                  const int64_t *path_off, int32_t n_paths)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_paths: null ctx");
+    if (!cx || !cy || !cyaw || !path_off || n_paths < 1) return fail(ctx, -22, "jsim_mpc_set_paths: bad argument");
+    if (path_off[0] != 0) return fail(ctx, -22, "jsim_mpc_set_paths: path_off[0] must be 0");
+    for (int i = 0; i < n_paths; ++i)
+        if (path_off[i + 1] <= path_off[i]) return fail(ctx, -22, "jsim_mpc_set_paths: path %d is empty", i);
+    const long long N = path_off[n_paths];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_paths(ctx);
+    // resident path table: xy interleaved (one 16-byte load per point in the nearest-index scan) + yaw
+    double2 *h = new (std::nothrow) double2[N];
+    if (!h) return fail(ctx, -12, "jsim_mpc_set_paths: out of host memory");
+    for (long long i = 0; i < N; ++i) { h[i].x = cx[i]; h[i].y = cy[i]; }
+    hipError_t e = hipMalloc(&ctx->d_pxy, sizeof(double2) * N);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_pyaw, sizeof(double) * N);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_poff, sizeof(long long) * (n_paths + 1));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_pxy, h, sizeof(double2) * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_pyaw, cyaw, sizeof(double) * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_poff, path_off, sizeof(long long) * (n_paths + 1), hipMemcpyHostToDevice);
+    delete[] h;
+    if (e != hipSuccess) { free_paths(ctx); return fail(ctx, -5, "jsim_mpc_set_paths: %s", hipGetErrorString(e)); }
+    ctx->n_paths = n_paths;
+    ctx->n_points = N;
+    return 0;
+}
+
+static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, const int32_t *path_len,
+                       const double *speed, int64_t *target_ind, double *oa, double *od, double *ox, double *oy,
+                       double *ov, double *oyaw, double *xref, uint32_t *active_mask, int32_t *status, int32_t *n_iter,
+                       double *xbar, int64_t *ref_idx, double *H, double *g, double *lam, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_step: null ctx");
+    if (B < 0) return fail(ctx, -22, "jsim_mpc_step: B=%d", B);
+    if (B == 0) return 0;
+    if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status)
+        return fail(ctx, -22, "jsim_mpc_step: a required device pointer is null");
+    if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_step: jsim_mpc_set_paths has not been called");
+    const jsim_cfg &c = ctx->cfg;
+    KP P;
+    memset(&P, 0, sizeof(P));
+    P.T = c.T; P.n = 2 * c.T; P.ld = 2 * c.T + 1; P.B = B;
+    P.dt = c.dt; P.dl = c.dl; P.L = c.L; P.w_perp = c.w_perp; P.w_para = c.w_para;
+    P.R0 = c.R[0]; P.R1 = c.R[1]; P.Rd0 = c.Rd[0]; P.Rd1 = c.Rd[1]; P.Qv = c.Q_v_yaw[0]; P.Qyaw = c.Q_v_yaw[1];
+    P.Qf0 = c.Qf[0] * c.T; P.Qf1 = c.Qf[1] * c.T; P.Qf2 = c.Qf[2] * c.T; P.Qf3 = c.Qf[3] * c.T; // mpc.py:28
+    P.Re0 = c.R_end[0]; P.Re1 = c.R_end[1];
+    P.dmax = c.max_dsteer * c.dt; P.amax = c.max_accel; P.amin = c.max_decel; P.smax = c.max_steer;
+    P.vmax_plant = c.max_speed; P.vmin = c.min_speed; P.vref_min = c.min_ref_speed;
+    P.pxy = ctx->d_pxy; P.pyaw = ctx->d_pyaw; P.poff = ctx->d_poff;
+    P.x0 = x0; P.path_id = path_id; P.path_len = path_len; P.speed = speed;
+    P.target_ind = (long long *)target_ind; P.oa = oa; P.od = od; P.ox = ox; P.oy = oy; P.ov = ov; P.oyaw = oyaw;
+    P.xref = xref; P.amask = active_mask; P.status = status; P.n_iter = n_iter;
+    P.dbg_xbar = xbar; P.dbg_idx = (long long *)ref_idx; P.dbg_H = H; P.dbg_g = g; P.dbg_lam = lam;
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t lds_bytes = jsim_lds_doubles(c.T) * sizeof(double);
+    if (lds_bytes > 160 * 1024) return fail(ctx, -22, "jsim_mpc_step: T=%d needs %zu B of LDS (> 160 KiB)", c.T, lds_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (P.n <= 64) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)mpc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
+    } else {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)mpc_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int jsim_mpc_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
+                             const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa,
+                             double *od, double *ox, double *oy, double *ov, double *oyaw, double *xref,
+                             uint32_t *active_mask, int32_t *status, int32_t *n_iter, void *stream)
+{
+    return launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref, active_mask,
+                       status, n_iter, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int jsim_mpc_step_debug(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
+                                   const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa,
+                                   double *od, double *ox, double *oy, double *ov, double *oyaw, double *xref,
+                                   uint32_t *active_mask, int32_t *status, int32_t *n_iter, double *xbar,
+                                   int64_t *ref_idx, double *H, double *g, double *lam, void *stream)
+{
+    return launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref, active_mask,
+                       status, n_iter, xbar, ref_idx, H, g, lam, stream);
+}
+
+extern "C" int jsim_plant_step(jsim_ctx *ctx, int32_t B, double *x0, const double *oa, const double *od,
+                               const int32_t *status, double *di_ai, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_plant_step: null ctx");
+    if (B < 0) return fail(ctx, -22, "jsim_plant_step: B=%d", B);
+    if (B == 0) return 0;
+    if (!x0 || !oa || !od || !status || !di_ai) return fail(ctx, -22, "jsim_plant_step: null device pointer");
+    const jsim_cfg &c = ctx->cfg;
+    PlantP P = {B, c.T, c.dt, c.L, c.max_steer, c.max_speed, c.min_speed, c.max_decel};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, x0, oa, od, status, di_ai);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
+                                            const int32_t *path_len, const int64_t *target_ind, const double *ox,
+                                            const double *oy, double *deviation, int32_t *is_goal, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_xref_deviation_goal: null ctx");
+    if (B < 0) return fail(ctx, -22, "jsim_mpc_xref_deviation_goal: B=%d", B);
+    if (B == 0) return 0;
+    if (!x0 || !path_id || !path_len || !target_ind || (deviation && (!ox || !oy)))
+        return fail(ctx, -22, "jsim_mpc_xref_deviation_goal: null device pointer");
+    if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_xref_deviation_goal: no paths set");
+    const jsim_cfg &c = ctx->cfg;
+    GoalP P = {B, c.T, c.goal_dis, c.stop_speed, ctx->d_pxy, ctx->d_pyaw, ctx->d_poff};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(deviation_goal_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, x0, path_id,
+                       path_len, (const long long *)target_ind, ox, oy, deviation, is_goal);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

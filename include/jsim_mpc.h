@@ -1,0 +1,112 @@
+/*
+ * jsim_mpc.h -- C-ABI of libjsim_mpc.so: the MI355X (gfx950) batched replacement for the reference's
+ * per-timestep MPC solve.  extern "C", plain pointers and sizes, no torch / C++ types.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo root):
+ *   jsim_mpc_create      <- module-level config load main/lib/mpc.py:15-39 (main/config/mpc_config.json)
+ *                           + MPC.__init__ scalars (dl, dt, car_dimensions.L)   main/lib/mpc.py:246-275
+ *   jsim_mpc_set_paths   <- MPC.__init__ cx/cy/cyaw + MPC.set_trajectory_fromarray  main/lib/mpc.py:257-261,279-282
+ *                           (truncation = per-ego path_len passed to jsim_mpc_step)
+ *   jsim_mpc_step        <- MPC.step -> _iterative_linear_mpc_control -> _calc_ref_trajectory,
+ *                           _predict_motion, _linear_mpc_control (cvxpy->ECOS)    main/lib/mpc.py:284-303,214-242,89-211
+ *                           with calc_nearest_index_in_direction                  main/lib/trajectories.py:100-126
+ *                           and Simulation.step / Bicycle.step for the rollout    main/lib/simulation.py:35-47, main/bicycle/main.py:28-41
+ *   jsim_plant_step      <- HistorySimulation.step / Simulation.step (the per-vehicle loop's plant update)
+ *                           main/lib/simulation.py:35-47,58-61 ; main/scenarios/mpc_intersection.py:163
+ *   jsim_mpc_xref_deviation_goal <- MPC.get_current_xref_deviation / MPC.is_goal  main/lib/mpc.py:305-330
+ *
+ * Conventions
+ *   - All array arguments of jsim_mpc_step / jsim_plant_step / ..._goal are DEVICE pointers (HBM), caller-owned,
+ *     no allocation inside those calls; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     jsim_mpc_set_paths takes HOST pointers (one-time upload into the context's resident path table).
+ *   - Ego-major rows: a wavefront owns one ego, so every per-ego array is one contiguous row
+ *     (x0 [B][4], oa/od [B][T], ox/oy/ov/oyaw [B][T+1], xref [B][4][T+1], active_mask [B][ceil(8T/32)]).
+ *   - State order is the MPC's [x, y, v, yaw] (main/lib/mpc.py:291), NOT State's (x, y, yaw, v).
+ *   - Return value: 0 on success, negative on error (-EINVAL style); never throws.  jsim_last_error()
+ *     returns a message for the last failing call on that context (or globally when ctx == NULL).
+ *   - Per-ego status (int32): 0 ok; 1 QP infeasible / not converged (reference: prints
+ *     "Error: Cannot solve mpc..." and returns None, main/lib/mpc.py:207-209 -- outputs ox..oyaw are left
+ *     untouched, oa/od are zeroed = the reference's cold start after None, caller applies ai = MAX_DECEL);
+ *     2 nearest-index anomaly (reference raises Exception("something wrong"), main/lib/trajectories.py:120 --
+ *     nothing but status is written for that ego).
+ *   - Active-constraint indices (bit i of active_mask) use the canonical row order of the reference's
+ *     constraint list main/lib/mpc.py:187-194:
+ *       D  steer-rate rows  2t (+), 2t+1 (-), t = 0..T-2        [0, 2T-2)
+ *       VU v_t <= speed,     t = 0..T                            [2T-2, 3T-1)
+ *       VL v_t >= MIN_SPEED, t = 0..T                            [3T-1, 4T)
+ *       AU a_t <= MAX_ACCEL                                      [4T, 5T)
+ *       AL a_t >= MAX_DECEL                                      [5T, 6T)
+ *       S  +-delta_t <= MAX_STEER rows 6T+2t (+), 6T+2t+1 (-)    [6T, 8T)
+ *     bit set <=> the row is in the final working set with multiplier > 1e-9 * max(1, ||g||_inf).
+ */
+#ifndef JSIM_MPC_H
+#define JSIM_MPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSIM_ABI_VERSION 1
+#define JSIM_MAX_T 48 /* two (2T)x(2T+1) fp64 tiles must fit the 160 KiB LDS of one CU */
+
+typedef struct jsim_cfg {
+    int32_t T;        /* horizon; 1 <= T <= JSIM_MAX_T (stock 13) */
+    int32_t max_iter; /* MAX_ITER; only 1 (the stock value) is supported */
+    double dt, dl, L;
+    double w_perp, w_para;
+    double R[2], Rd[2], Q_v_yaw[2];
+    double Qf[4];     /* as in the JSON; multiplied by T inside (main/lib/mpc.py:28) */
+    double R_end[2];  /* diag(10,10), main/lib/mpc.py:181 */
+    double max_dsteer; /* rad/s */
+    double max_accel, max_decel;
+    double max_steer, max_speed, min_speed; /* Simulation.* main/lib/simulation.py:23-25 */
+    double min_ref_speed;                   /* 10/3.6, main/lib/mpc.py:99 */
+    double goal_dis, stop_speed;
+} jsim_cfg;
+
+typedef struct jsim_ctx jsim_ctx;
+
+enum { JSIM_OK = 0, JSIM_INFEASIBLE = 1, JSIM_NEAREST_ANOMALY = 2 };
+
+int jsim_abi_version(void);
+const char *jsim_last_error(const jsim_ctx *ctx);
+
+int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **out);
+void jsim_mpc_destroy(jsim_ctx *ctx);
+
+/* HOST pointers.  cyaw must already be smoothed (MPC.__init__ does it on the host, in place). */
+int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double *cy, const double *cyaw,
+                       const int64_t *path_off /*[n_paths+1]*/, int32_t n_paths);
+
+/* One MPC.step for B egos.  In/out: target_ind [B], oa/od [B][T] (warm start in, solution out).
+ * Optional outputs may be NULL: ox, oy, ov, oyaw, xref, active_mask, n_iter. */
+int jsim_mpc_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
+                  const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa,
+                  double *od, double *ox, double *oy, double *ov, double *oyaw, double *xref,
+                  uint32_t *active_mask, int32_t *status, int32_t *n_iter, void *stream);
+
+/* Same, plus stage-level outputs for parity tests (any may be NULL):
+ * xbar [B][4][T+1], ref_idx [B][T+1], H [B][2T][2T] (lower triangle valid), g [B][2T], lam [B][8T]. */
+int jsim_mpc_step_debug(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
+                        const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa,
+                        double *od, double *ox, double *oy, double *ov, double *oyaw, double *xref,
+                        uint32_t *active_mask, int32_t *status, int32_t *n_iter, double *xbar,
+                        int64_t *ref_idx, double *H, double *g, double *lam, void *stream);
+
+/* Controller output + plant update for B egos: (di, ai) = (od[b][0], oa[b][0]) when status[b]==0, else
+ * ai = MAX_DECEL and di = di_prev[b] (main/lib/mpc.py:298-303); then Simulation.step on x0 in place.
+ * di_ai [B][2] in/out (previous steer in, applied (steer, accel) out). */
+int jsim_plant_step(jsim_ctx *ctx, int32_t B, double *x0, const double *oa, const double *od,
+                    const int32_t *status, double *di_ai, void *stream);
+
+/* deviation [B] (needs ox[b][0], oy[b][0]) and is_goal [B] (int32 0/1); goal = last point of the FULL path. */
+int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
+                                 const int32_t *path_len, const int64_t *target_ind, const double *ox,
+                                 const double *oy, double *deviation, int32_t *is_goal, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

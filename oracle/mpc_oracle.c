@@ -90,9 +90,9 @@ int orc_nearest_index_in_direction(double x, double y, const double *cx, const d
 }
 
 /* ------------------------------------------------------------------------------------------------
- * main/lib/mpc.py:89-112  _calc_ref_trajectory  (ov=None branch: the only one taken with MAX_ITER=1;
- * with MAX_ITER>1 the reference feeds the previous solve's ov -- handled by the caller passing sv<0?
- * No: see orc_calc_ref_trajectory_ov below.)
+ * main/lib/mpc.py:89-112  _calc_ref_trajectory.  ov_in == NULL is the reference's ov=None branch (the
+ * only one taken with the stock MAX_ITER=1); with MAX_ITER>1 the reference feeds the previous pass's
+ * solved speeds, which orc_mpc_step passes as ov_in.
  * ---------------------------------------------------------------------------------------------- */
 static int calc_ref_trajectory_impl(const orc_params *p, double sx, double sy, double sv,
                                     const double *ov_in, const double *cx, const double *cy,
@@ -683,6 +683,10 @@ int orc_mpc_step_batch(const orc_params *p, int32_t B, const double *x0, const i
             if (oy) memcpy(&oy[(size_t)b * W], o.oy, sizeof(double) * W);
             if (ov) memcpy(&ov[(size_t)b * W], o.ov, sizeof(double) * W);
             if (oyaw) memcpy(&oyaw[(size_t)b * W], o.oyaw, sizeof(double) * W);
+        }
+        if (st == ORC_INFEASIBLE) { /* batched form of "outputs None -> next call cold-starts from zeros" */
+            if (oa) memset(&oa[(size_t)b * T], 0, sizeof(double) * T);
+            if (od) memset(&od[(size_t)b * T], 0, sizeof(double) * T);
         }
         if (xref && st != ORC_NEAREST_ANOMALY)
             memcpy(&xref[(size_t)b * 4 * W], o.xref, sizeof(double) * 4 * W);

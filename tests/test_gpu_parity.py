@@ -1,0 +1,276 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs, and
+against the golden vectors produced by the reference's own functions.  Run with -m gpu on an MI355X.
+
+Bars: path indices / target_ind / reaches_end / status bit-exact; rollout and reference window <= 1e-12;
+condensed (H, g) <= 1e-9 relative; control sequence u* <= 1e-4 abs (north_star; observed ~1e-9);
+active-constraint indices identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TS = (13, 20, 30, 40)
+U_TOL = 1e-4  # north_star tolerance on u*
+
+
+def _engine(pkg, routes, batch, T):
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, device="cuda:0",
+                         smooth=False)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    return eng
+
+
+def _debug_bufs(eng):
+    B, T = eng.B, eng.T
+    f = dict(dtype=torch.float64, device=eng.device)
+    return {"xbar": torch.zeros(B, 4, T + 1, **f), "ref_idx": torch.zeros(B, T + 1, dtype=torch.int64, device=eng.device),
+            "H": torch.zeros(B, 2 * T, 2 * T, **f), "g": torch.zeros(B, 2 * T, **f), "lam": torch.zeros(B, 8 * T, **f)}
+
+
+def _oracle_batch(oracle, pkg, routes, batch, T, **kw):
+    p = oracle.make_params(T=T, **kw)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    return p, oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off,
+                                    batch.target_ind, batch.oa, batch.od)
+
+
+@pytest.mark.parametrize("T", TS)
+def test_stages_vs_reference_golden(pkg, routes, T):
+    """S1-S3 on the GPU against what the reference's _calc_ref_trajectory/_predict_motion returned."""
+    g = load_golden(f"stages_T{T}.npz")
+    batch = pkg.synth.EgoBatch(x0=g["x0"], path_id=g["path_id"], path_len=g["path_len"],
+                               target_ind=g["target_ind_in"], speed=np.full(len(g["x0"]), 30 / 3.6),
+                               oa=g["oa"], od=g["od"])
+    eng = _engine(pkg, routes, batch, T)
+    dbg = _debug_bufs(eng)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device), debug=dbg)
+    torch.cuda.synchronize()
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st == 2, g["status"] == 2)
+    ok = g["status"] == 0
+    assert np.array_equal(eng.target_ind.cpu().numpy()[ok], g["target_ind_out"][ok])
+    assert np.array_equal(eng.xref.cpu().numpy()[ok], g["xref"][ok])                       # gathered points: bit-exact
+    ridx = dbg["ref_idx"].cpu().numpy()
+    assert np.array_equal((ridx == (g["path_len"][:, None] - 1))[ok], g["reaches_end"][ok])
+    feas = ok & (st != 1)
+    np.testing.assert_allclose(dbg["xbar"].cpu().numpy()[feas], g["xbar"][feas], rtol=0, atol=1e-12)
+    assert feas.sum() > 60
+
+
+@pytest.mark.parametrize("T", TS)
+def test_step_vs_oracle(pkg, oracle, routes, T):
+    B = 192 if T <= 20 else 96
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=0, truncate=True, near_end_frac=0.2)
+    batch.x0[5, 2] = 9.5       # v0 > speed  -> infeasible constant row (reference failure path)
+    batch.x0[6, 2] = -5.5      # v0 < MIN_SPEED
+    eng = _engine(pkg, routes, batch, T)
+    dbg = _debug_bufs(eng)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device), debug=dbg)
+    torch.cuda.synchronize()
+    p, ref = _oracle_batch(oracle, pkg, routes, batch, T)
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st, ref["status"])
+    assert st[5] == 1 and st[6] == 1
+    assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy(), ref["xref"])
+    ok = st == 0
+    assert ok.sum() >= B - 8
+    oa, od = eng.oa.cpu().numpy(), eng.od.cpu().numpy()
+    err_u = max(np.abs(oa - ref["oa"])[ok].max(), np.abs(od - ref["od"])[ok].max())
+    assert err_u <= U_TOL, err_u
+    assert err_u <= 1e-7, err_u   # what fp64 actually delivers (cond(H) up to ~1e8 at T=40)
+    assert np.all(oa[~ok] == 0) and np.all(od[~ok] == 0)   # failure -> cold start next tick
+    for name in ("ox", "oy", "ov", "oyaw"):
+        np.testing.assert_allclose(getattr(eng, name).cpu().numpy()[ok], ref[name][ok], rtol=0, atol=1e-6)
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])   # bit-exact active sets
+    assert np.array_equal(eng.n_iter.cpu().numpy(), ref["n_iter"])   # same sequence of active-set decisions
+    # condensed QP of a few egos against the oracle's dense build
+    H = dbg["H"].cpu().numpy(); gg = dbg["g"].cpu().numpy()
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    for b in np.flatnonzero(ok)[:12]:
+        o = off[batch.path_id[b]]
+        r = oracle.mpc_step(p, (batch.x0[b, 0], batch.x0[b, 1], batch.x0[b, 3], batch.x0[b, 2]),
+                            cx[o:o + batch.path_len[b]], cy[o:o + batch.path_len[b]], cyaw[o:o + batch.path_len[b]],
+                            int(batch.target_ind[b]), batch.speed[b], oa=batch.oa[b], od=batch.od[b], want_qp=True)
+        assert np.abs(H[b] - r["H"]).max() <= 1e-9 * np.abs(r["H"]).max()
+        assert np.abs(gg[b] - r["g"]).max() <= 1e-9 * max(1.0, np.abs(r["g"]).max())
+        np.testing.assert_allclose(dbg["lam"].cpu().numpy()[b], r["lam"], rtol=1e-6, atol=1e-6 * max(1.0, np.abs(r["g"]).max()))
+
+
+def test_kkt_property_at_full_size(pkg, routes):
+    """Size-independent property at the bench configuration (B=256, T=20) and at config 3's shape
+    (B=4096, T=30): the returned u* satisfies the KKT conditions of the condensed QP the kernel built
+    (strictly convex => that IS the optimum), and active rows are tight."""
+    for B, T in ((256, 20), (4096, 30)):
+        batch = pkg.synth.make_ego_batch(routes, B, T, seed=1, truncate=(T == 30))
+        eng = _engine(pkg, routes, batch, T)
+        dbg = _debug_bufs(eng)
+        eng.solve(torch.from_numpy(batch.x0).to(eng.device), debug=dbg)
+        torch.cuda.synchronize()
+        st = eng.status
+        assert int((st == 0).sum()) >= B - 2
+        ok = st == 0
+        H = dbg["H"]; H = torch.tril(H) + torch.tril(H, -1).transpose(1, 2)
+        u = torch.stack([eng.oa, eng.od], dim=2).reshape(B, 2 * T)
+        lam = dbg["lam"]
+        n, m = 2 * T, 8 * T
+        # G rows from the structure (canonical order), built once
+        G = torch.zeros(m, n, dtype=torch.float64, device=eng.device)
+        for t in range(T - 1):
+            G[2 * t, 2 * t + 3] = 1; G[2 * t, 2 * t + 1] = -1; G[2 * t + 1] = -G[2 * t]
+        for t in range(T + 1):
+            G[2 * T - 2 + t, 0:2 * t:2] = eng.dt
+            G[3 * T - 1 + t] = -G[2 * T - 2 + t]
+        for t in range(T):
+            G[4 * T + t, 2 * t] = 1; G[5 * T + t, 2 * t] = -1
+            G[6 * T + 2 * t, 2 * t + 1] = 1; G[6 * T + 2 * t + 1, 2 * t + 1] = -1
+        c = eng.config
+        h = torch.zeros(B, m, dtype=torch.float64, device=eng.device)
+        x0 = torch.from_numpy(batch.x0).to(eng.device)
+        h[:, :2 * T - 2] = c.max_dsteer_rad * eng.dt
+        h[:, 2 * T - 2:3 * T - 1] = (eng.speed - x0[:, 2])[:, None]
+        h[:, 3 * T - 1:4 * T] = (x0[:, 2] - c.MIN_SPEED)[:, None]
+        h[:, 4 * T:5 * T] = c.MAX_ACCEL
+        h[:, 5 * T:6 * T] = -c.MAX_DECEL
+        h[:, 6 * T:] = c.MAX_STEER_RAD
+        stat = torch.einsum("bij,bj->bi", H, u) + dbg["g"] + lam @ G
+        scale = dbg["g"].abs().amax(dim=1).clamp(min=1.0)
+        assert float((stat.abs().amax(dim=1) / scale)[ok].max()) <= 1e-8
+        slack = h - u @ G.T
+        assert float((-slack)[ok].max()) <= 1e-8                       # primal feasible
+        assert float(lam[ok].min()) >= 0.0                             # dual feasible
+        assert float((lam * slack).abs()[ok].max() / float(scale.max())) <= 1e-8   # complementary
+        # active bits <=> positive multipliers
+        words = eng.active_mask.cpu().numpy().view(np.uint32)
+        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, -1)[:, :m].astype(bool)
+        thr = (1e-9 * scale).cpu().numpy()[:, None]
+        assert np.array_equal(bits[ok.cpu().numpy()], (lam.cpu().numpy() > thr)[ok.cpu().numpy()])
+
+
+def test_empty_batch_and_bad_args(pkg, routes):
+    eng = pkg.BatchedMPC(routes, np.zeros(0, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
+    eng.solve(torch.zeros(0, 4, dtype=torch.float64, device=eng.device))   # B = 0 is a no-op
+    with pytest.raises(ValueError):
+        eng.solve(torch.zeros(1, 4, dtype=torch.float64, device=eng.device))
+    with pytest.raises(pkg._cabi.JsimError):
+        pkg.BatchedMPC(routes, [0], dl=pkg.synth.DL, T=64, smooth=False)      # T above JSIM_MAX_T
+    with pytest.raises(ValueError):
+        e2 = pkg.BatchedMPC(routes, [0, 1], dl=pkg.synth.DL, T=13, smooth=False)
+        e2.set_path_len(np.array([0, 5]))
+
+
+def test_nearest_index_anomaly_status(pkg):
+    """The hairpin of the golden fixture: the reference raises Exception('something wrong'); the batch
+    reports status 2 for that ego and touches nothing else of it; the single-ego MPC raises."""
+    g = load_golden("nearest_index.npz")
+    hair = g["hairpin"]
+    path = np.concatenate([hair, np.zeros((len(hair), 1))], axis=1)
+    cases = g["hairpin_cases"]
+    B = len(cases)
+    eng = pkg.BatchedMPC([path], np.zeros(B, dtype=np.int32), dl=0.05, T=13, smooth=False)
+    x0 = np.zeros((B, 4)); x0[:, 0] = cases[:, 0]; x0[:, 1] = cases[:, 1]; x0[:, 2] = 1.0
+    eng.oa.fill_(0.25)
+    eng.solve(torch.from_numpy(x0).to(eng.device))
+    torch.cuda.synchronize()
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st == 2, cases[:, 3] == 2)
+    an = st == 2
+    assert an.sum() >= 3
+    assert np.all(eng.oa.cpu().numpy()[an] == 0.25) and np.all(eng.target_ind.cpu().numpy()[an] == 0)
+    good = cases[:, 3] == 0
+    assert np.array_equal(eng.target_ind.cpu().numpy()[good], cases[good, 2].astype(np.int64))
+    b = int(np.flatnonzero(an)[0])
+    mpc = pkg.MPC(path[:, 0].copy(), path[:, 1].copy(), path[:, 2].copy(), 0.05, pkg.BicycleModelDimensions())
+    with pytest.raises(Exception, match="something wrong"):
+        mpc.step(pkg.State(x=x0[b, 0], y=x0[b, 1], yaw=0.0, v=1.0))
+
+
+def test_single_ego_dropin_closed_loop(pkg, oracle, routes):
+    """The reference's controller surface for one ego (config 1 shape: T=13 stock), driven closed loop for 40
+    ticks with a truncated path part of the way; every tick compared with the oracle on the same inputs."""
+    r = routes[0].copy()
+    car = pkg.BicycleModelDimensions()
+    cyaw = r[:, 2].copy()
+    mpc = pkg.MPC(cx=r[:, 0], cy=r[:, 1], cyaw=cyaw, dl=pkg.synth.DL, car_dimensions=car, speed=30 / 3.6, dt=0.2)
+    p = oracle.make_params(T=13)
+    st = np.array([r[0, 0], r[0, 1], 0.0, r[0, 2]])       # x, y, v, yaw
+    tind, oa, od = 0, None, None
+    for k in range(40):
+        cutoff = len(r) if (k < 10 or k > 25) else 260      # emulate a collision cut-off (mpc_intersection.py:129-143)
+        traj = r[:cutoff]
+        mpc.set_trajectory_fromarray(traj)
+        di, ai = mpc.step(pkg.State(x=st[0], y=st[1], yaw=st[3], v=st[2]))
+        ref = oracle.mpc_step(p, (st[0], st[1], st[3], st[2]), traj[:, 0], traj[:, 1], traj[:, 2], tind, 30 / 3.6,
+                              oa=oa, od=od)
+        assert mpc.status == ref["status"] == 0
+        assert mpc.target_ind == ref["target_ind"]
+        assert abs(di - ref["od"][0]) <= U_TOL and abs(ai - ref["oa"][0]) <= U_TOL
+        np.testing.assert_allclose(mpc.oa, ref["oa"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(mpc.odelta, ref["od"], rtol=0, atol=1e-7)
+        assert mpc.active_constraints == ref["active"]
+        np.testing.assert_allclose(mpc.ox, ref["ox"], rtol=0, atol=1e-7)
+        assert np.array_equal(mpc.xref, ref["xref"])
+        dev = mpc.get_current_xref_deviation()
+        assert abs(dev - oracle.xref_deviation(traj[:, 0], traj[:, 1], traj[:, 2], mpc.target_ind, ref["ox"][0], ref["oy"][0])) < 1e-7
+        assert mpc.is_goal(pkg.State(x=st[0], y=st[1], yaw=st[3], v=st[2])) == \
+            oracle.is_goal(p, st[0], st[1], st[2], (r[-1, 0], r[-1, 1]), mpc.target_ind, cutoff)
+        # feed the ORACLE's outputs forward so both sides keep seeing identical inputs
+        tind, oa, od = ref["target_ind"], ref["oa"], ref["od"]
+        mpc.target_ind = tind
+        mpc._engine.oa.copy_(torch.from_numpy(oa)[None]); mpc._engine.od.copy_(torch.from_numpy(od)[None])
+        st = oracle.plant_step(p, st, ref["oa"][0], ref["od"][0])
+    assert st[2] > 3.0   # the ego actually drove
+
+
+def test_failure_path_single_ego(pkg, routes, capsys):
+    r = routes[1].copy()
+    mpc = pkg.MPC(cx=r[:, 0], cy=r[:, 1], cyaw=r[:, 2].copy(), dl=pkg.synth.DL,
+                  car_dimensions=pkg.BicycleModelDimensions(), speed=5.0)
+    mpc.di = 0.123
+    di, ai = mpc.step(pkg.State(x=r[10, 0], y=r[10, 1], yaw=r[10, 2], v=8.0))   # v0 > speed
+    assert (di, ai) == (0.123, pkg.MAX_DECEL)                # mpc.py:298-303
+    assert mpc.oa is None and mpc.ox is None
+    assert "Error: Cannot solve mpc..." in capsys.readouterr().err
+    with pytest.raises(TypeError):
+        mpc.get_current_xref_deviation()                     # the reference's latent bug, preserved
+
+
+def test_plant_and_goal_kernels(pkg, oracle, routes):
+    g = load_golden("misc.npz")
+    B = len(g["plant_in"])
+    eng = pkg.BatchedMPC(routes, np.zeros(B, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
+    x0 = torch.from_numpy(np.ascontiguousarray(g["plant_in"][:, :4])).to(eng.device)
+    eng.oa[:, 0] = torch.from_numpy(g["plant_in"][:, 4]).to(eng.device)
+    eng.od[:, 0] = torch.from_numpy(g["plant_in"][:, 5]).to(eng.device)
+    eng.status.zero_()
+    eng.status[3] = 1
+    eng.di_ai[3, 0] = 0.2
+    pkg._cabi.check(eng.lib.jsim_plant_step(eng._ctx, B, x0.data_ptr(), eng.oa.data_ptr(), eng.od.data_ptr(),
+                                            eng.status.data_ptr(), eng.di_ai.data_ptr(), None), eng._ctx)
+    torch.cuda.synchronize()
+    out = x0.cpu().numpy()
+    keep = np.arange(B) != 3
+    np.testing.assert_allclose(out[keep], g["plant_out"][keep], rtol=0, atol=1e-12)    # reference Simulation.step
+    p = oracle.make_params(T=13)
+    exp = oracle.plant_step(p, g["plant_in"][3, :4], p.max_decel, 0.2)                  # failure path: MAX_DECEL, old di
+    np.testing.assert_allclose(out[3], exp, rtol=0, atol=1e-12)
+    assert tuple(eng.di_ai[3].cpu().numpy()) == (0.2, p.max_decel)
+    # deviation / goal against the reference's golden values
+    dev_rows, goal_rows = g["deviation"], g["goal"]
+    n = len(dev_rows)
+    eng2 = pkg.BatchedMPC(routes, np.zeros(n, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
+    eng2.target_ind.copy_(torch.from_numpy(dev_rows[:, 0].astype(np.int64)))
+    eng2.ox[:, 0] = torch.from_numpy(dev_rows[:, 1]).to(eng2.device)
+    eng2.oy[:, 0] = torch.from_numpy(dev_rows[:, 2]).to(eng2.device)
+    x = torch.zeros(n, 4, dtype=torch.float64, device=eng2.device)
+    dev, _ = eng2.xref_deviation_and_goal(x)
+    np.testing.assert_allclose(dev.cpu().numpy(), dev_rows[:, 3], rtol=0, atol=1e-12)
+    eng2.target_ind.copy_(torch.from_numpy(goal_rows[:, 0].astype(np.int64)).clamp(max=len(routes[0]) - 1))
+    x[:, 0] = torch.from_numpy(goal_rows[:, 1]); x[:, 1] = torch.from_numpy(goal_rows[:, 2]); x[:, 2] = torch.from_numpy(goal_rows[:, 3])
+    inr = goal_rows[:, 0] < len(routes[0])    # target_ind == len(cx) cannot be dereferenced for the deviation
+    eng2.target_ind.copy_(torch.from_numpy(np.minimum(goal_rows[:, 0], len(routes[0]) - 1).astype(np.int64)))
+    _, goal = eng2.xref_deviation_and_goal(x)
+    assert np.array_equal(goal.cpu().numpy()[inr], goal_rows[inr, 4].astype(bool))
