@@ -30,7 +30,8 @@ class JsimCfg(C.Structure):
 
 EXPORTS = (
     "jsim_abi_version", "jsim_last_error", "jsim_mpc_create", "jsim_mpc_destroy", "jsim_mpc_set_paths",
-    "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_mpc_xref_deviation_goal",
+    "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance",
+    "jsim_mpc_xref_deviation_goal",
 )
 
 _lib = None
@@ -67,6 +68,8 @@ def load() -> C.CDLL:
     lib.jsim_mpc_step_debug.argtypes = [vp, i32] + [vp] * 21
     lib.jsim_plant_step.restype = C.c_int
     lib.jsim_plant_step.argtypes = [vp, i32] + [vp] * 6
+    lib.jsim_loop_advance.restype = C.c_int
+    lib.jsim_loop_advance.argtypes = [vp, i32] + [vp] * 11 + [i32, vp, vp, i32, vp, vp]
     lib.jsim_mpc_xref_deviation_goal.restype = C.c_int
     lib.jsim_mpc_xref_deviation_goal.argtypes = [vp, i32] + [vp] * 9
     if lib.jsim_abi_version() != ABI_VERSION:

@@ -59,12 +59,19 @@ struct KP {
     double *dbg_xbar;
     long long *dbg_idx;
     double *dbg_H, *dbg_g, *dbg_lam;
+    long long *dbg_clk; // diagnostic build only (-DJSIM_STAMPS): [B][16] s_memtime stamps at phase boundaries
 };
 
 // ---------------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
 // ---------------------------------------------------------------------------------------------------
 #define LDS_SYNC() __syncthreads() /* single-wave workgroup: orders LDS traffic, the barrier itself is free */
+
+#ifdef JSIM_STAMPS
+#define STAMP(i) do { if (P.dbg_clk && lane == 0) P.dbg_clk[(size_t)ego * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ double rdlane(double v, int l)
 {
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     const double speed = P.speed[ego];
     const double dt = P.dt;
 
+    STAMP(0);
     // ------------------------------------------------------------------ S1: nearest index in direction
     long long tind = s0;
     int status = JSIM_OK;
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         return;
     }
 
+    STAMP(1);
     // ------------------------------------------------------------------ S1: travel -> idx -> xref
     const int tl_idx = lane < T ? lane : T; // lanes > T mirror lane T (keeps loads in range)
     double xr, yr, yawr;
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     // infeasible constant rows x[2,0] <= speed, x[2,0] >= MIN_SPEED (ECOS feasibility tolerance)
     if (speed - sv < -JSIM_FEAS_TOL || sv - P.vmin < -JSIM_FEAS_TOL) status = JSIM_INFEASIBLE;
 
+    STAMP(2);
     // ------------------------------------------------------------------ S2: rollout of the warm start
     const bool tl = lane < T;
     double wa_t = tl ? P.oa[(size_t)ego * T + lane] : 0.0;
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         return;
     }
 
+    STAMP(3);
     // ------------------------------------------------------------------ S3: linearisation coefficients (lane t < T)
     double al = 0, be = 0, alp = 0, bep = 0, ccx = 0, ccy = 0, kt = 0;
     if (tl) {
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     }
     LDS_SYNC();
 
+    STAMP(4);
     // ------------------------------------------------------------------ S4a: H = 2 S'QS on the fp64 matrix cores
     // v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
     // D[row = (lane>>4) + 4*reg][col = lane&15].  k = state component of time step t; tile columns = 8 time steps.
@@ -411,6 +423,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     }
     LDS_SYNC();
 
+    STAMP(5);
     // input cost R / R_end (mpc.py:180-183), input-difference cost Rd (mpc.py:186), and g = 2 S'Q(f - xref)
     double gmax;
     {
@@ -460,6 +473,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         }
     }
 
+    STAMP(6);
     // ------------------------------------------------------------------ S4b: Cholesky H = L L' (in place, lower), lane = row
     for (int k = 0; k < n; ++k) {
         double s[RPL];
@@ -489,6 +503,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         LDS_SYNC();
     }
 
+    STAMP(7);
     // ------------------------------------------------------------------ J = L^-T : lane r owns row r, J[r][i] = (L^-1)[i][r]
     for (int i = 0; i < n; ++i) {
         double s[RPL];
@@ -511,6 +526,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     }
     LDS_SYNC();
 
+    STAMP(8);
     // ------------------------------------------------------------------ unconstrained optimum u = -J J' g
     double u[RPL];
     {
@@ -553,6 +569,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     }
     LDS_SYNC();
 
+    STAMP(9);
     // ------------------------------------------------------------------ Goldfarb-Idnani dual active-set iterations
     int q = 0, iters = 0;
     const int max_iters = 50 * n + 100;
@@ -804,6 +821,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         if (failed) { status = JSIM_INFEASIBLE; break; }
     }
 
+    STAMP(10);
     // ------------------------------------------------------------------ S5: outputs
     if (status != JSIM_OK) {
         if (tl) { P.oa[(size_t)ego * T + lane] = 0.0; P.od[(size_t)ego * T + lane] = 0.0; }
@@ -856,6 +874,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         P.target_ind[ego] = tind;
         if (P.n_iter) P.n_iter[ego] = iters;
     }
+    STAMP(11);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -887,6 +906,66 @@ __global__ __launch_bounds__(256) void plant_step_kernel(PlantP P, double *x0, c
     v = (P.vmin > v) ? P.vmin : v;
     x0[4 * b] = x; x0[4 * b + 1] = y; x0[4 * b + 2] = v; x0[4 * b + 3] = th;
 }
+
+// Closed-loop bookkeeping of the per-vehicle loop for a batch (main/scenarios/mpc_intersection.py:99-163):
+// (di, ai) selection + plant step as above, history record, and replacement of finished egos -- the loop's
+// `if mpc.is_goal(state): break` (:101) becomes "respawn at the ego's spawn state with a cold controller".
+struct LoopP {
+    int B, T, max_age;
+    double dt, L, smax, vmax, vmin, max_decel, goal_dis, stop_speed;
+    const double2 *pxy;
+    const long long *poff;
+};
+
+__global__ __launch_bounds__(256) void loop_advance_kernel(LoopP P, double *x0, double *oa, double *od,
+                                                           const int *status, double *di_ai, long long *target_ind,
+                                                           const int *path_id, const int *path_len,
+                                                           const double *x0_spawn, const long long *target_spawn,
+                                                           int *age, double *hist, int *tick, int hist_cap,
+                                                           unsigned long long *n_respawn)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    double di = di_ai[2 * b], ai;
+    if (status[b] == JSIM_OK) { di = od[(size_t)b * P.T]; ai = oa[(size_t)b * P.T]; }
+    else ai = P.max_decel;
+    di_ai[2 * b] = di;
+    di_ai[2 * b + 1] = ai;
+    if (hist) {
+        const int k = *tick; // device tick counter: bumped by a 1-thread kernel after this one (graph-replay safe)
+        if (k < hist_cap) { hist[((size_t)k * P.B + b) * 2] = di; hist[((size_t)k * P.B + b) * 2 + 1] = ai; }
+    }
+    double x = x0[4 * b], y = x0[4 * b + 1], v = x0[4 * b + 2], th = x0[4 * b + 3];
+    double dc = (P.smax < di) ? P.smax : di;
+    dc = (-P.smax > dc) ? -P.smax : dc;
+    const double xd = v * cos(th), yd = v * sin(th), thd = (v / P.L) * tan(dc);
+    x += xd * P.dt; y += yd * P.dt; th += thd * P.dt;
+    v += ai * P.dt;
+    v = (P.vmax < v) ? P.vmax : v;
+    v = (P.vmin > v) ? P.vmin : v;
+    // MPC.is_goal on the new state (main/lib/mpc.py:314-330)
+    const long long off = P.poff[path_id[b]];
+    const long long full = P.poff[path_id[b] + 1] - off;
+    const double2 g = P.pxy[off + full - 1];
+    const long long ti = target_ind[b];
+    bool isgoal = hypot(x - g.x, y - g.y) <= P.goal_dis;
+    long long df = ti - (long long)path_len[b];
+    if ((df < 0 ? -df : df) >= 5) isgoal = false;
+    const bool done = (isgoal && fabs(v) <= P.stop_speed) || (age[b] + 1 >= P.max_age);
+    if (done) {
+        x = x0_spawn[4 * b]; y = x0_spawn[4 * b + 1]; v = x0_spawn[4 * b + 2]; th = x0_spawn[4 * b + 3];
+        target_ind[b] = target_spawn[b];
+        for (int t = 0; t < P.T; ++t) { oa[(size_t)b * P.T + t] = 0.0; od[(size_t)b * P.T + t] = 0.0; }
+        di_ai[2 * b] = 0.0; di_ai[2 * b + 1] = 0.0;
+        age[b] = 0;
+        if (n_respawn) atomicAdd(n_respawn, 1ull);
+    } else {
+        age[b] += 1;
+    }
+    x0[4 * b] = x; x0[4 * b + 1] = y; x0[4 * b + 2] = v; x0[4 * b + 3] = th;
+}
+
+__global__ void tick_increment_kernel(int *tick) { *tick += 1; }
 
 struct GoalP {
     int B, T;
@@ -936,6 +1015,8 @@ struct jsim_ctx {
     long long *d_poff;
     int n_paths;
     long long n_points;
+    size_t lds_bytes;
+    long long *dbg_clk; // diagnostic builds only
     char err[512];
 };
 
@@ -975,11 +1056,19 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(nullptr, -19, "jsim_mpc_create: no HIP device");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -22, "jsim_mpc_create: device %d of %d", device_id, ndev);
+    const size_t lds_bytes = jsim_lds_doubles(cfg->T) * sizeof(double);
+    if (lds_bytes > 160 * 1024) return fail(nullptr, -22, "jsim_mpc_create: T=%d needs %zu B of LDS (> 160 KiB)", cfg->T, lds_bytes);
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    // dynamic LDS above the 64 KiB default has to be granted per kernel; done once here so that the step call
+    // itself is pure launches (it may be captured into a hipGraph)
+    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     jsim_ctx *c = new (std::nothrow) jsim_ctx();
     if (!c) return fail(nullptr, -12, "jsim_mpc_create: out of memory");
     memset(c, 0, sizeof(*c));
     c->cfg = *cfg;
     c->device = device_id;
+    c->lds_bytes = lds_bytes;
     *out = c;
     return 0;
 }
@@ -1055,18 +1144,12 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
     P.target_ind = (long long *)target_ind; P.oa = oa; P.od = od; P.ox = ox; P.oy = oy; P.ov = ov; P.oyaw = oyaw;
     P.xref = xref; P.amask = active_mask; P.status = status; P.n_iter = n_iter;
     P.dbg_xbar = xbar; P.dbg_idx = (long long *)ref_idx; P.dbg_H = H; P.dbg_g = g; P.dbg_lam = lam;
+    P.dbg_clk = ctx->dbg_clk;
 
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t lds_bytes = jsim_lds_doubles(c.T) * sizeof(double);
-    if (lds_bytes > 160 * 1024) return fail(ctx, -22, "jsim_mpc_step: T=%d needs %zu B of LDS (> 160 KiB)", c.T, lds_bytes);
+    const size_t lds_bytes = ctx->lds_bytes;
     hipStream_t s = (hipStream_t)stream;
-    if (P.n <= 64) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)mpc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
-    } else {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)mpc_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
-    }
+    if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
+    else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -1123,3 +1206,37 @@ extern "C" int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const doub
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+extern "C" int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *oa, double *od, const int32_t *status,
+                                 double *di_ai, int64_t *target_ind, const int32_t *path_id, const int32_t *path_len,
+                                 const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age,
+                                 double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_advance: null ctx");
+    if (B < 0) return fail(ctx, -22, "jsim_loop_advance: B=%d", B);
+    if (B == 0) return 0;
+    if (!x0 || !oa || !od || !status || !di_ai || !target_ind || !path_id || !path_len || !x0_spawn || !target_spawn || !age)
+        return fail(ctx, -22, "jsim_loop_advance: null device pointer");
+    if (hist && !tick) return fail(ctx, -22, "jsim_loop_advance: hist needs a device tick counter");
+    if (!ctx->d_pxy) return fail(ctx, -22, "jsim_loop_advance: no paths set");
+    const jsim_cfg &c = ctx->cfg;
+    LoopP P = {B, c.T, max_age > 0 ? max_age : 0x7fffffff, c.dt, c.L, c.max_steer, c.max_speed, c.min_speed,
+               c.max_decel, c.goal_dis, c.stop_speed, ctx->d_pxy, ctx->d_poff};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loop_advance_kernel, dim3((B + 255) / 256), dim3(256), 0, s, P, x0, oa, od, status, di_ai,
+                       (long long *)target_ind, path_id, path_len, x0_spawn, (const long long *)target_spawn, age, hist,
+                       tick, hist_cap, (unsigned long long *)n_respawn);
+    if (tick) hipLaunchKernelGGL(tick_increment_kernel, dim3(1), dim3(1), 0, s, tick);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+#ifdef JSIM_STAMPS
+// diagnostic build only (not declared in include/jsim_mpc.h, not built into libjsim_mpc.so)
+extern "C" int jsim_debug_set_clock_buffer(jsim_ctx *ctx, long long *dev_buf)
+{
+    if (!ctx) return -22;
+    ctx->dbg_clk = dev_buf;
+    return 0;
+}
+#endif

@@ -13,6 +13,8 @@
  *                           and Simulation.step / Bicycle.step for the rollout    main/lib/simulation.py:35-47, main/bicycle/main.py:28-41
  *   jsim_plant_step      <- HistorySimulation.step / Simulation.step (the per-vehicle loop's plant update)
  *                           main/lib/simulation.py:35-47,58-61 ; main/scenarios/mpc_intersection.py:163
+ *   jsim_loop_advance    <- the rest of the loop body: plant update, history, `if mpc.is_goal(state): break`
+ *                           main/scenarios/mpc_intersection.py:99-101,163 ; main/lib/simulation.py:64-88 (History)
  *   jsim_mpc_xref_deviation_goal <- MPC.get_current_xref_deviation / MPC.is_goal  main/lib/mpc.py:305-330
  *
  * Conventions
@@ -100,6 +102,17 @@ int jsim_mpc_step_debug(jsim_ctx *ctx, int32_t B, const double *x0, const int32_
  * di_ai [B][2] in/out (previous steer in, applied (steer, accel) out). */
 int jsim_plant_step(jsim_ctx *ctx, int32_t B, double *x0, const double *oa, const double *od,
                     const int32_t *status, double *di_ai, void *stream);
+
+/* One tick of closed-loop bookkeeping for a batch, the rest of the per-vehicle loop body
+ * (main/scenarios/mpc_intersection.py:99-163): (di, ai) selection + plant step as jsim_plant_step, optional
+ * history record hist[tick][B][2] (tick = a device counter this call increments, so the call can be replayed
+ * from a hipGraph), and replacement of finished egos: an ego for which MPC.is_goal holds on its new state
+ * (main/lib/mpc.py:314-330; the loop's `break`, :101) or whose age reaches max_age ticks (<=0: never) restarts
+ * from x0_spawn/target_spawn with a cold controller (oa = od = 0, di = ai = 0). n_respawn (optional) counts them. */
+int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *oa, double *od, const int32_t *status,
+                      double *di_ai, int64_t *target_ind, const int32_t *path_id, const int32_t *path_len,
+                      const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age,
+                      double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream);
 
 /* deviation [B] (needs ox[b][0], oy[b][0]) and is_goal [B] (int32 0/1); goal = last point of the FULL path. */
 int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,

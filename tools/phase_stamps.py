@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostic: where one mpc_step_kernel launch spends its cycles.  Builds csrc/jsim_mpc.hip with
+-DJSIM_STAMPS into a SEPARATE library (libjsim_mpc_stamps.so; the shipped library carries no stamps),
+runs the bench workload for a few ticks and prints per-phase cycle shares (median over egos).
+Never quote this build's run time -- read its shares."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+pkg = importlib.import_module("av-simulation-at-intersections_amd")
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+lib = os.path.join(REPO, "av-simulation-at-intersections_amd", "libjsim_mpc_stamps.so")
+subprocess.check_call([pkg.build._hipcc()] + pkg.build.HIPCC_FLAGS + ["-DJSIM_STAMPS", "-I", pkg.build.INC, pkg.build.SRC, "-o", lib])
+pkg._cabi.LIB_PATH = lib
+pkg._cabi._lib = None
+S = pkg.synth
+routes = S.make_route_table()
+for r in routes:
+    S.smooth_yaw_inplace(r[:, 2])
+batch = S.make_ego_batch(routes, B, T, seed=1)
+eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smooth=False)
+eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+x0 = torch.from_numpy(batch.x0).cuda()
+loop = pkg.ClosedLoop(eng, x0, max_age=400)
+clk = torch.zeros(B, 16, dtype=torch.int64, device="cuda")
+eng.lib.jsim_debug_set_clock_buffer.argtypes = [C.c_void_p, C.c_void_p]
+eng.lib.jsim_debug_set_clock_buffer(eng._ctx, C.c_void_p(clk.data_ptr()))
+names = ["S1 nearest", "S1 idx/xref", "S2 rollout", "S3 coef+scans", "S4a H mfma", "g + R/Rd", "cholesky", "J=L^-T",
+         "u0=-JJ'g", "active-set loop", "S5 outputs"]
+acc = np.zeros((0, 11))
+for tick in range(30):
+    loop.tick()
+    torch.cuda.synchronize()
+    c = clk.cpu().numpy()
+    ok = (eng.status.cpu().numpy() == 0)
+    acc = np.concatenate([acc, np.diff(c[ok][:, :12], axis=1)])
+it = eng.n_iter.cpu().numpy()
+tot = acc.sum(axis=1)
+print(f"T={T} B={B}: total cycles/ego median {np.median(tot):.0f} (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f}); "
+      f"last-tick mean n_iter {it.mean():.1f}")
+for k, nme in enumerate(names):
+    print(f"  {nme:18s} median {np.median(acc[:, k]):10.0f} cyc  {100 * acc[:, k].sum() / tot.sum():5.1f} %")
