@@ -45,6 +45,19 @@ class ClosedLoop:
             _ptr(self.target_spawn), _ptr(self.age), self.max_age, _ptr(self.hist), _ptr(self.tick_counter),
             self.hist_cap, _ptr(self.n_respawn), eng._stream()), eng._ctx, "jsim_loop_advance")
 
+    def run(self, n_ticks: int):
+        """n_ticks ticks in one call (jsim_mpc_run_ticks): for T = 13 / 20 a single launch in which each wavefront
+        advances its own ego n_ticks times -- same results as n_ticks x tick(), without per-tick synchronisation."""
+        eng = self.eng
+        eng._check_x0(self.x0)
+        _cabi.check(eng.lib.jsim_mpc_run_ticks(
+            eng._ctx, eng.B, int(n_ticks), _ptr(self.x0), _ptr(eng.path_id), _ptr(eng.path_len), _ptr(eng.speed),
+            _ptr(eng.target_ind), _ptr(eng.oa), _ptr(eng.od), _ptr(eng.ox), _ptr(eng.oy), _ptr(eng.ov), _ptr(eng.oyaw),
+            _ptr(eng.xref), _ptr(eng.active_mask), _ptr(eng.status), _ptr(eng.n_iter), _ptr(eng.di_ai),
+            _ptr(self.x0_spawn), _ptr(self.target_spawn), _ptr(self.age), self.max_age, _ptr(self.hist),
+            _ptr(self.tick_counter), self.hist_cap, _ptr(self.n_respawn), eng._stream()), eng._ctx,
+            "jsim_mpc_run_ticks")
+
     # ---- hipGraph: a launch-bound inner loop (two short kernels per tick) replayed without host work
     def capture(self, ticks: int):
         """Capture `ticks` consecutive ticks into one hipGraph (all pointers are fixed device buffers and the

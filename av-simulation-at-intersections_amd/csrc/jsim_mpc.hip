@@ -27,6 +27,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -60,6 +61,8 @@ struct KP {
     long long *dbg_idx;
     double *dbg_H, *dbg_g, *dbg_lam;
     long long *dbg_clk; // diagnostic build only (-DJSIM_STAMPS): [B][16] s_memtime stamps at phase boundaries
+    int dbg_max_gi;     // timing experiments only (env JSIM_DEBUG_MAX_GI): stop the active-set loop after this many
+                        // outer iterations (results are then NOT the optimum); -1 = off
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -877,6 +880,8 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     STAMP(11);
 }
 
+#include "mpc_step_reg.inc"
+
 // ---------------------------------------------------------------------------------------------------
 // plant update for the per-vehicle loop (Simulation.step, main/lib/simulation.py:35-47) and the
 // controller's (di, ai) selection with the failure path (main/lib/mpc.py:298-303)
@@ -966,6 +971,7 @@ __global__ __launch_bounds__(256) void loop_advance_kernel(LoopP P, double *x0, 
 }
 
 __global__ void tick_increment_kernel(int *tick) { *tick += 1; }
+__global__ void tick_add_kernel(int *tick, int n) { *tick += n; }
 
 struct GoalP {
     int B, T;
@@ -1016,6 +1022,8 @@ struct jsim_ctx {
     int n_paths;
     long long n_points;
     size_t lds_bytes;
+    int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
+    int dbg_max_gi;
     long long *dbg_clk; // diagnostic builds only
     char err[512];
 };
@@ -1069,6 +1077,13 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     c->cfg = *cfg;
     c->device = device_id;
     c->lds_bytes = lds_bytes;
+    // register-resident fast path: instantiated for the stock horizon (13) and the benchmark horizon (20);
+    // JSIM_FORCE_LDS_KERNEL=1 routes those through the generic LDS-resident kernel too (used by the tests to
+    // cover both kernels on the same inputs)
+    const char *force = getenv("JSIM_FORCE_LDS_KERNEL");
+    c->use_reg_kernel = (cfg->T == 13 || cfg->T == 20) && !(force && force[0] == '1');
+    const char *mg = getenv("JSIM_DEBUG_MAX_GI");
+    c->dbg_max_gi = mg ? atoi(mg) : -1;
     *out = c;
     return 0;
 }
@@ -1118,6 +1133,20 @@ extern "C" int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double 
     return 0;
 }
 
+static void fill_kp(const jsim_ctx *ctx, int32_t B, KP &P)
+{
+    const jsim_cfg &c = ctx->cfg;
+    memset(&P, 0, sizeof(P));
+    P.T = c.T; P.n = 2 * c.T; P.ld = 2 * c.T + 1; P.B = B;
+    P.dt = c.dt; P.dl = c.dl; P.L = c.L; P.w_perp = c.w_perp; P.w_para = c.w_para;
+    P.R0 = c.R[0]; P.R1 = c.R[1]; P.Rd0 = c.Rd[0]; P.Rd1 = c.Rd[1]; P.Qv = c.Q_v_yaw[0]; P.Qyaw = c.Q_v_yaw[1];
+    P.Qf0 = c.Qf[0] * c.T; P.Qf1 = c.Qf[1] * c.T; P.Qf2 = c.Qf[2] * c.T; P.Qf3 = c.Qf[3] * c.T; // mpc.py:28
+    P.Re0 = c.R_end[0]; P.Re1 = c.R_end[1];
+    P.dmax = c.max_dsteer * c.dt; P.amax = c.max_accel; P.amin = c.max_decel; P.smax = c.max_steer;
+    P.vmax_plant = c.max_speed; P.vmin = c.min_speed; P.vref_min = c.min_ref_speed;
+    P.pxy = ctx->d_pxy; P.pyaw = ctx->d_pyaw; P.poff = ctx->d_poff;
+}
+
 static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, const int32_t *path_len,
                        const double *speed, int64_t *target_ind, double *oa, double *od, double *ox, double *oy,
                        double *ov, double *oyaw, double *xref, uint32_t *active_mask, int32_t *status, int32_t *n_iter,
@@ -1131,24 +1160,24 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
     if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_step: jsim_mpc_set_paths has not been called");
     const jsim_cfg &c = ctx->cfg;
     KP P;
-    memset(&P, 0, sizeof(P));
-    P.T = c.T; P.n = 2 * c.T; P.ld = 2 * c.T + 1; P.B = B;
-    P.dt = c.dt; P.dl = c.dl; P.L = c.L; P.w_perp = c.w_perp; P.w_para = c.w_para;
-    P.R0 = c.R[0]; P.R1 = c.R[1]; P.Rd0 = c.Rd[0]; P.Rd1 = c.Rd[1]; P.Qv = c.Q_v_yaw[0]; P.Qyaw = c.Q_v_yaw[1];
-    P.Qf0 = c.Qf[0] * c.T; P.Qf1 = c.Qf[1] * c.T; P.Qf2 = c.Qf[2] * c.T; P.Qf3 = c.Qf[3] * c.T; // mpc.py:28
-    P.Re0 = c.R_end[0]; P.Re1 = c.R_end[1];
-    P.dmax = c.max_dsteer * c.dt; P.amax = c.max_accel; P.amin = c.max_decel; P.smax = c.max_steer;
-    P.vmax_plant = c.max_speed; P.vmin = c.min_speed; P.vref_min = c.min_ref_speed;
-    P.pxy = ctx->d_pxy; P.pyaw = ctx->d_pyaw; P.poff = ctx->d_poff;
+    fill_kp(ctx, B, P);
     P.x0 = x0; P.path_id = path_id; P.path_len = path_len; P.speed = speed;
     P.target_ind = (long long *)target_ind; P.oa = oa; P.od = od; P.ox = ox; P.oy = oy; P.ov = ov; P.oyaw = oyaw;
     P.xref = xref; P.amask = active_mask; P.status = status; P.n_iter = n_iter;
     P.dbg_xbar = xbar; P.dbg_idx = (long long *)ref_idx; P.dbg_H = H; P.dbg_g = g; P.dbg_lam = lam;
     P.dbg_clk = ctx->dbg_clk;
+    P.dbg_max_gi = ctx->dbg_max_gi;
 
     const size_t lds_bytes = ctx->lds_bytes;
     hipStream_t s = (hipStream_t)stream;
-    if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
+    TickP K;
+    memset(&K, 0, sizeof(K));
+    K.n_ticks = 1; // plain MPC.step: one tick, no plant/bookkeeping
+    if (ctx->use_reg_kernel && c.T == 13)
+        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), jsim_reg_lds_doubles(13) * sizeof(double), s, P, K);
+    else if (ctx->use_reg_kernel && c.T == 20)
+        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), jsim_reg_lds_doubles(20) * sizeof(double), s, P, K);
+    else if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
     else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -1240,3 +1269,53 @@ extern "C" int jsim_debug_set_clock_buffer(jsim_ctx *ctx, long long *dev_buf)
     return 0;
 }
 #endif
+
+extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id,
+                                  const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa,
+                                  double *od, double *ox, double *oy, double *ov, double *oyaw, double *xref,
+                                  uint32_t *active_mask, int32_t *status, int32_t *n_iter, double *di_ai,
+                                  const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age,
+                                  double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_run_ticks: null ctx");
+    if (B < 0 || n_ticks < 0) return fail(ctx, -22, "jsim_mpc_run_ticks: B=%d n_ticks=%d", B, n_ticks);
+    if (B == 0 || n_ticks == 0) return 0;
+    if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status || !di_ai || !x0_spawn ||
+        !target_spawn || !age)
+        return fail(ctx, -22, "jsim_mpc_run_ticks: a required device pointer is null");
+    if (hist && !tick) return fail(ctx, -22, "jsim_mpc_run_ticks: hist needs a device tick counter");
+    if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_run_ticks: jsim_mpc_set_paths has not been called");
+    const jsim_cfg &c = ctx->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    if (!(ctx->use_reg_kernel && (c.T == 13 || c.T == 20))) {
+        // horizons without the fused register kernel: the same ticks as separate launches
+        for (int k = 0; k < n_ticks; ++k) {
+            int rc = launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref,
+                                 active_mask, status, n_iter, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+            if (rc) return rc;
+            rc = jsim_loop_advance(ctx, B, x0, oa, od, status, di_ai, target_ind, path_id, path_len, x0_spawn,
+                                   target_spawn, age, max_age, hist, tick, hist_cap, n_respawn, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    KP P;
+    fill_kp(ctx, B, P);
+    P.x0 = x0; P.path_id = path_id; P.path_len = path_len; P.speed = speed;
+    P.target_ind = (long long *)target_ind; P.oa = oa; P.od = od; P.ox = ox; P.oy = oy; P.ov = ov; P.oyaw = oyaw;
+    P.xref = xref; P.amask = active_mask; P.status = status; P.n_iter = n_iter;
+    P.dbg_clk = nullptr; P.dbg_max_gi = ctx->dbg_max_gi;
+    TickP K;
+    memset(&K, 0, sizeof(K));
+    K.n_ticks = n_ticks; K.advance = 1; K.max_age = max_age > 0 ? max_age : 0x7fffffff; K.hist_cap = hist_cap;
+    K.max_decel = c.max_decel; K.goal_dis = c.goal_dis; K.stop_speed = c.stop_speed;
+    K.x0w = x0; K.di_ai = di_ai; K.x0_spawn = x0_spawn; K.target_spawn = (const long long *)target_spawn; K.age = age;
+    K.hist = hist; K.tick = tick; K.n_respawn = (unsigned long long *)n_respawn;
+    if (c.T == 13)
+        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), jsim_reg_lds_doubles(13) * sizeof(double), s, P, K);
+    else
+        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), jsim_reg_lds_doubles(20) * sizeof(double), s, P, K);
+    if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

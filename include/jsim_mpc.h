@@ -15,6 +15,7 @@
  *                           main/lib/simulation.py:35-47,58-61 ; main/scenarios/mpc_intersection.py:163
  *   jsim_loop_advance    <- the rest of the loop body: plant update, history, `if mpc.is_goal(state): break`
  *                           main/scenarios/mpc_intersection.py:99-101,163 ; main/lib/simulation.py:64-88 (History)
+ *   jsim_mpc_run_ticks   <- `for i in itertools.count():` itself, main/scenarios/mpc_intersection.py:99 (K iterations per call)
  *   jsim_mpc_xref_deviation_goal <- MPC.get_current_xref_deviation / MPC.is_goal  main/lib/mpc.py:305-330
  *
  * Conventions
@@ -113,6 +114,17 @@ int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *oa, double *
                       double *di_ai, int64_t *target_ind, const int32_t *path_id, const int32_t *path_len,
                       const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age,
                       double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream);
+
+/* n_ticks consecutive closed-loop ticks, each = jsim_mpc_step followed by jsim_loop_advance, with identical results.
+ * For the horizons that have the fused register-resident kernel (T = 13, 20) this is ONE launch in which every
+ * wavefront runs all n_ticks for its own ego (egos are independent, so none waits for the slowest solve of a tick);
+ * other horizons fall back to 2 * n_ticks launches.  The per-step outputs (ox .. n_iter) hold the LAST tick's values. */
+int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id,
+                       const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa, double *od,
+                       double *ox, double *oy, double *ov, double *oyaw, double *xref, uint32_t *active_mask,
+                       int32_t *status, int32_t *n_iter, double *di_ai, const double *x0_spawn,
+                       const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist, int32_t *tick,
+                       int32_t hist_cap, uint64_t *n_respawn, void *stream);
 
 /* deviation [B] (needs ox[b][0], oy[b][0]) and is_goal [B] (int32 0/1); goal = last point of the FULL path. */
 int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,

@@ -279,3 +279,29 @@ def test_plant_and_goal_kernels(pkg, oracle, routes):
     eng2.target_ind.copy_(torch.from_numpy(np.minimum(goal_rows[:, 0], len(routes[0]) - 1).astype(np.int64)))
     _, goal = eng2.xref_deviation_and_goal(x)
     assert np.array_equal(goal.cpu().numpy()[inr], goal_rows[inr, 4].astype(bool))
+
+
+@pytest.mark.parametrize("T", (13, 20, 30))
+def test_fused_ticks_equal_single_ticks(pkg, routes, T):
+    """jsim_mpc_run_ticks (one launch, every wavefront runs K ticks of its own ego) must reproduce K x
+    (jsim_mpc_step + jsim_loop_advance) bit for bit: same history, same final state, same respawn count.
+    T = 30 exercises the multi-launch fallback of the same entry point."""
+    B, K = 96, 60
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=11, near_end_frac=0.5)
+    def make():
+        eng = _engine(pkg, routes, batch, T)
+        x0 = torch.from_numpy(batch.x0).to(eng.device)
+        return eng, pkg.ClosedLoop(eng, x0, hist_cap=K, max_age=45)
+    e1, l1 = make()
+    for _ in range(K):
+        l1.tick()
+    e2, l2 = make()
+    l2.run(25); l2.run(35)
+    torch.cuda.synchronize()
+    assert int(l1.tick_counter.item()) == int(l2.tick_counter.item()) == K
+    assert torch.equal(l1.hist, l2.hist)
+    assert torch.equal(l1.x0, l2.x0)
+    for name in ("oa", "od", "ox", "oy", "ov", "oyaw", "xref", "target_ind", "status", "n_iter", "active_mask", "di_ai"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    assert torch.equal(l1.age, l2.age)
+    assert int(l1.n_respawn.item()) == int(l2.n_respawn.item()) > 0
