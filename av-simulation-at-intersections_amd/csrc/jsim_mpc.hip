@@ -1174,9 +1174,9 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
     memset(&K, 0, sizeof(K));
     K.n_ticks = 1; // plain MPC.step: one tick, no plant/bookkeeping
     if (ctx->use_reg_kernel && c.T == 13)
-        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), jsim_reg_lds_doubles(13) * sizeof(double), s, P, K);
+        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
     else if (ctx->use_reg_kernel && c.T == 20)
-        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), jsim_reg_lds_doubles(20) * sizeof(double), s, P, K);
+        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
     else if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
     else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
     HIP_TRY(ctx, hipGetLastError());
@@ -1312,9 +1312,9 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     K.x0w = x0; K.di_ai = di_ai; K.x0_spawn = x0_spawn; K.target_spawn = (const long long *)target_spawn; K.age = age;
     K.hist = hist; K.tick = tick; K.n_respawn = (unsigned long long *)n_respawn;
     if (c.T == 13)
-        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), jsim_reg_lds_doubles(13) * sizeof(double), s, P, K);
+        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
     else
-        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), jsim_reg_lds_doubles(20) * sizeof(double), s, P, K);
+        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

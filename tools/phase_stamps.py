@@ -31,21 +31,31 @@ eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smo
 eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
 x0 = torch.from_numpy(batch.x0).cuda()
 loop = pkg.ClosedLoop(eng, x0, max_age=400)
-clk = torch.zeros(B, 16, dtype=torch.int64, device="cuda")
+clk = torch.zeros(B * 24, dtype=torch.int64, device="cuda")
 eng.lib.jsim_debug_set_clock_buffer.argtypes = [C.c_void_p, C.c_void_p]
 eng.lib.jsim_debug_set_clock_buffer(eng._ctx, C.c_void_p(clk.data_ptr()))
 names = ["S1 nearest", "S1 idx/xref", "S2 rollout", "S3 coef+scans", "S4a H mfma", "g + R/Rd", "cholesky", "J=L^-T",
          "u0=-JJ'g", "active-set loop", "S5 outputs"]
 acc = np.zeros((0, 11))
+gacc = np.zeros((0, 8)); itacc = np.zeros(0)
 for tick in range(30):
     loop.tick()
     torch.cuda.synchronize()
-    c = clk.cpu().numpy()
+    call = clk.cpu().numpy()
+    c = call[:B * 16].reshape(B, 16)
     ok = (eng.status.cpu().numpy() == 0)
     acc = np.concatenate([acc, np.diff(c[ok][:, :12], axis=1)])
+    gacc = np.concatenate([gacc, call[B * 16:].reshape(B, 8)[ok]])
+    itacc = np.concatenate([itacc, eng.n_iter.cpu().numpy()[ok]])
 it = eng.n_iter.cpu().numpy()
 tot = acc.sum(axis=1)
 print(f"T={T} B={B}: total cycles/ego median {np.median(tot):.0f} (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f}); "
       f"last-tick mean n_iter {it.mean():.1f}")
 for k, nme in enumerate(names):
     print(f"  {nme:18s} median {np.median(acc[:, k]):10.0f} cyc  {100 * acc[:, k].sum() / tot.sum():5.1f} %")
+
+gn = ["step1 argmax", "publish row", "reduce d", "dots z,y", "backsubst", "ratio+step", "add (Householder)", "drop (Givens)"]
+tot_it = itacc.sum()
+print(f"active-set loop: {tot_it:.0f} iterations over {len(itacc)} solves (mean {itacc.mean():.1f}); cycles per iteration by section:")
+for k, nme in enumerate(gn):
+    print(f"  {nme:20s} {gacc[:, k].sum() / max(tot_it, 1):8.0f} cyc/iter   {100 * gacc[:, k].sum() / gacc.sum():5.1f} %")
