@@ -164,6 +164,13 @@ def main():
         nbytes = algorithmic_bytes_per_step(T) * B * ticks_per_launch
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = nbytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(REPO, "profiles", "r01_bench_fused_pmc_summary.json")
+        if mode == "fused" and T == 20 and B == 256 and os.path.exists(pmc_path):
+            # HBM bytes of one 50-tick launch from the rocprofv3 PMC passes of this same command (profiles/r01_SUMMARY.txt):
+            # FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request), WRITE_SIZE as is, both in KiB; scaled to this chunk
+            pmc = json.load(open(pmc_path))
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (ticks_per_launch / 50.0)
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",
             "value": value, "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -176,7 +183,7 @@ def main():
                        "mean_active_set_iters": round(mean_iter, 2), "failed_egos_last_tick": n_fail,
                        "respawns": int(loop.n_respawn.item())},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": f"mpc_step_reg_kernel<{T}>" if T in (13, 20) else "mpc_step_kernel", "kernel_ms": kern_ms,
                          "ticks_per_launch": ticks_per_launch,
                          "algorithmic_flops_per_launch": flops,

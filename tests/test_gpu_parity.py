@@ -305,3 +305,29 @@ def test_fused_ticks_equal_single_ticks(pkg, routes, T):
         assert torch.equal(getattr(e1, name), getattr(e2, name)), name
     assert torch.equal(l1.age, l2.age)
     assert int(l1.n_respawn.item()) == int(l2.n_respawn.item()) > 0
+
+
+@pytest.mark.parametrize("T", (13, 20))
+def test_lds_kernel_and_register_kernel_agree(pkg, oracle, routes, T, monkeypatch):
+    """T = 13 / 20 normally run the register-resident kernel; JSIM_FORCE_LDS_KERNEL=1 (read at jsim_mpc_create)
+    routes them through the generic LDS-resident kernel.  Both must match the oracle and each other."""
+    B = 128
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=5, truncate=True, near_end_frac=0.3)
+    x0 = torch.from_numpy(batch.x0).cuda()
+    e_reg = _engine(pkg, routes, batch, T)
+    e_reg.solve(x0)
+    monkeypatch.setenv("JSIM_FORCE_LDS_KERNEL", "1")
+    e_lds = _engine(pkg, routes, batch, T)
+    monkeypatch.delenv("JSIM_FORCE_LDS_KERNEL")
+    e_lds.solve(x0)
+    torch.cuda.synchronize()
+    p, ref = _oracle_batch(oracle, pkg, routes, batch, T)
+    for eng in (e_reg, e_lds):
+        assert np.array_equal(eng.status.cpu().numpy(), ref["status"])
+        assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+        assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
+        ok = ref["status"] == 0
+        assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-8
+        assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-8
+    assert float((e_reg.oa - e_lds.oa).abs().max()) <= 1e-8
+    assert torch.equal(e_reg.xref, e_lds.xref)
