@@ -38,8 +38,12 @@ def gather_rows(local: torch.Tensor, B: int, group=None) -> torch.Tensor:
     if local.shape[0] < per:
         pad = torch.zeros((per - local.shape[0],) + tuple(tail), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()  # rehearsal on a box without RCCL peers: gloo moves host memory only
     out = torch.empty((world * per,) + tuple(tail), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    out = out.to(dev)
     if all(s == per for s in sizes):
         return out
     return torch.cat([out[r * per: r * per + sizes[r]] for r in range(world)], dim=0)

@@ -66,11 +66,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # JSIM_BENCH_REHEARSAL=1: all ranks share GPU 0 and the final gather runs over gloo -- lets the N>1 code path be
+    # exercised on a one-GPU box (the real run is one rank per GPU with RCCL)
+    rehearsal = os.environ.get("JSIM_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     pkg = importlib.import_module("av-simulation-at-intersections_amd")
     S = pkg.synth
@@ -125,7 +132,7 @@ def main():
         assert hist_all.shape[0] == B * world
     sync_all()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cpu" if rehearsal else device)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
