@@ -31,6 +31,7 @@ class JsimCfg(C.Structure):
 EXPORTS = (
     "jsim_abi_version", "jsim_last_error", "jsim_mpc_create", "jsim_mpc_destroy", "jsim_mpc_set_paths",
     "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance", "jsim_mpc_run_ticks",
+    "jsim_loop_set_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
     "jsim_mpc_xref_deviation_goal",
 )
 
@@ -70,6 +71,12 @@ def load() -> C.CDLL:
     lib.jsim_plant_step.argtypes = [vp, i32] + [vp] * 6
     lib.jsim_loop_advance.restype = C.c_int
     lib.jsim_loop_advance.argtypes = [vp, i32] + [vp] * 11 + [i32, vp, vp, i32, vp, vp]
+    lib.jsim_loop_set_geometry.restype = C.c_int
+    lib.jsim_loop_set_geometry.argtypes = [vp, dbl, dbl, dbl]
+    lib.jsim_loop_predict_obstacles.restype = C.c_int
+    lib.jsim_loop_predict_obstacles.argtypes = [vp, i32, vp, i32, vp, vp]
+    lib.jsim_loop_pre_tick.restype = C.c_int
+    lib.jsim_loop_pre_tick.argtypes = [vp, i32] + [vp] * 9 + [i32, i32, vp, vp, vp]
     lib.jsim_mpc_run_ticks.restype = C.c_int
     lib.jsim_mpc_run_ticks.argtypes = [vp, i32, i32] + [vp] * 19 + [i32, vp, vp, i32, vp, vp]
     lib.jsim_mpc_xref_deviation_goal.restype = C.c_int

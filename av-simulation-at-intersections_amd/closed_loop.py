@@ -9,6 +9,8 @@ from typing import Optional
 import numpy as np
 import torch
 
+import math
+
 from . import _cabi
 from .batched import BatchedMPC, _ptr
 
@@ -78,3 +80,63 @@ class ClosedLoop:
     def replay(self):
         self._graph.replay()
         return self._graph_ticks
+
+
+def car_circles(L: float = 2.86, width: float = 2.0, extra_length: float = 0.64):
+    """Collision circles of the reference's BicycleModelDimensions (main/lib/car_dimensions.py:62-79,82-90): bounding
+    box (width, L + 0.64), radius = width / sqrt(2), two centres on the body axis at L/2 +- (length/2 - width/2) from the
+    rear axle.  Returns (radius, (front_offset, rear_offset))."""
+    length = L + extra_length
+    offset = length / 2 - width / 2
+    return width / (2 ** .5), (L / 2 + offset, L / 2 - offset)
+
+
+class PreTick:
+    """The loop glue ahead of MPC.step (main/scenarios/mpc_intersection.py:104-143) for the whole batch: progress index,
+    ego-path resampling, obstacle prediction, collision check, cut-off -> writes the engine's `path_len`, i.e. the batched
+    `mpc.set_trajectory_fromarray(trajectory_full[:cutoff_idx])`.  Obstacles are shared by all egos of the batch."""
+
+    def __init__(self, engine: BatchedMPC, frame_window: int = 10, time_horizon: float = 7.0, car_width: float = 2.0,
+                 extra_length: float = 0.64):
+        self.eng = engine
+        eng = engine
+        self.radius, (c0, c1) = car_circles(eng.L, car_width, extra_length)
+        self.frame_window = int(frame_window)
+        self.n_steps = int(math.ceil(time_horizon / eng.dt - 1e-9))          # len(np.arange(0, horizon, dt))
+        self.margin = 4 * int(math.ceil(self.radius / eng.dl))               # EXTRA_CUTOFF_MARGIN, :88-89
+        _cabi.check(eng.lib.jsim_loop_set_geometry(eng._ctx, c0, c1, self.radius), eng._ctx, "jsim_loop_set_geometry")
+        dev, B = eng.device, eng.B
+        self.traj_idx = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.prev_len = torch.full((B,), -1, dtype=torch.int32, device=dev)   # tmp_trajectory is None
+        self.col_flag = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.col_xy = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        self.first_idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.pred = None
+        self.n_obs = 0
+        self.predict(torch.zeros(0, 6, dtype=torch.float64, device=dev))
+
+    def predict(self, obst: torch.Tensor):
+        """obst: device float64 [n_obs, 6] = (x, y, v, yaw, a, steer) per obstacle, as MovingObstacle*.get() returns."""
+        eng = self.eng
+        if not (obst.is_cuda and obst.dtype == torch.float64 and obst.dim() == 2 and obst.shape[1] == 6 and obst.is_contiguous()):
+            raise ValueError("obst must be a contiguous float64 device tensor [n_obs, 6]")
+        self.n_obs = int(obst.shape[0])
+        self.pred = torch.zeros(max(self.n_obs, 1), self.n_steps, 3, dtype=torch.float64, device=eng.device)
+        _cabi.check(eng.lib.jsim_loop_predict_obstacles(eng._ctx, self.n_obs, _ptr(obst) if self.n_obs else None,
+                                                        self.n_steps, _ptr(self.pred), eng._stream()), eng._ctx,
+                    "jsim_loop_predict_obstacles")
+        return self.pred[: self.n_obs]
+
+    def run(self, x0: torch.Tensor, debug: Optional[dict] = None):
+        """Updates traj_idx and the engine's path_len for this tick (then remembers it as the previous truncated path)."""
+        eng = self.eng
+        eng._check_x0(x0)
+        dbg_idx = dbg_n = None
+        if debug is not None:
+            dbg_idx, dbg_n = debug["res_idx"], debug["n_res"]
+        _cabi.check(eng.lib.jsim_loop_pre_tick(
+            eng._ctx, eng.B, _ptr(x0), _ptr(eng.path_id), _ptr(self.traj_idx), _ptr(self.prev_len), _ptr(eng.path_len),
+            _ptr(self.col_flag), _ptr(self.col_xy), _ptr(self.first_idx), _ptr(self.status), self.frame_window,
+            self.margin, _ptr(dbg_idx), _ptr(dbg_n), eng._stream()), eng._ctx, "jsim_loop_pre_tick")
+        self.prev_len.copy_(eng.path_len)

@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "jsim_mpc.h"
 
@@ -881,6 +882,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
 }
 
 #include "mpc_step_reg.inc"
+#include "loop_pre_tick.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // plant update for the per-vehicle loop (Simulation.step, main/lib/simulation.py:35-47) and the
@@ -1021,6 +1023,13 @@ struct jsim_ctx {
     long long *d_poff;
     int n_paths;
     long long n_points;
+    // per-vehicle loop glue (row f1): host copy of the paths, car circle geometry, per-point circle centres, predictions
+    double *h_cx, *h_cy, *h_cyaw;
+    int have_geom;
+    double cc0, cc1, col_radius;
+    double2 *d_pcc;
+    double2 *d_pred_cc;
+    int pred_n_obs, pred_n_steps;
     size_t lds_bytes;
     int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
     int dbg_max_gi;
@@ -1093,6 +1102,9 @@ static void free_paths(jsim_ctx *c)
     if (c->d_pxy) (void)hipFree(c->d_pxy);
     if (c->d_pyaw) (void)hipFree(c->d_pyaw);
     if (c->d_poff) (void)hipFree(c->d_poff);
+    if (c->d_pcc) (void)hipFree(c->d_pcc);
+    delete[] c->h_cx; delete[] c->h_cy; delete[] c->h_cyaw;
+    c->h_cx = c->h_cy = c->h_cyaw = nullptr; c->d_pcc = nullptr;
     c->d_pxy = nullptr; c->d_pyaw = nullptr; c->d_poff = nullptr;
     c->n_paths = 0; c->n_points = 0;
 }
@@ -1102,7 +1114,26 @@ extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_paths(ctx);
+    if (ctx->d_pred_cc) (void)hipFree(ctx->d_pred_cc);
     delete ctx;
+}
+
+// circle centres of every path point (lib/trajectories.py:11-55 with the two body-axis circles of
+// lib/car_dimensions.py:66-79): (cos(yaw) * x_off - sin(yaw) * 0.0) + x, (sin(yaw) * x_off + cos(yaw) * 0.0) + y
+static int upload_circle_centres(jsim_ctx *ctx)
+{
+    const long long N = ctx->n_points;
+    if (N <= 0 || !ctx->h_cx) return 0;
+    std::vector<double2> h((size_t)2 * N);
+    for (long long i = 0; i < N; ++i) {
+        const double c = std::cos(ctx->h_cyaw[i]), s = std::sin(ctx->h_cyaw[i]);
+        h[2 * i].x = c * ctx->cc0 - s * 0.0 + ctx->h_cx[i];     h[2 * i].y = s * ctx->cc0 + c * 0.0 + ctx->h_cy[i];
+        h[2 * i + 1].x = c * ctx->cc1 - s * 0.0 + ctx->h_cx[i]; h[2 * i + 1].y = s * ctx->cc1 + c * 0.0 + ctx->h_cy[i];
+    }
+    if (ctx->d_pcc) { (void)hipFree(ctx->d_pcc); ctx->d_pcc = nullptr; }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pcc, sizeof(double2) * 2 * N));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_pcc, h.data(), sizeof(double2) * 2 * N, hipMemcpyHostToDevice));
+    return 0;
 }
 
 extern "C" int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double *cy, const double *cyaw,
@@ -1130,6 +1161,10 @@ extern "C" int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double 
     if (e != hipSuccess) { free_paths(ctx); return fail(ctx, -5, "jsim_mpc_set_paths: %s", hipGetErrorString(e)); }
     ctx->n_paths = n_paths;
     ctx->n_points = N;
+    ctx->h_cx = new (std::nothrow) double[N]; ctx->h_cy = new (std::nothrow) double[N]; ctx->h_cyaw = new (std::nothrow) double[N];
+    if (!ctx->h_cx || !ctx->h_cy || !ctx->h_cyaw) return fail(ctx, -12, "jsim_mpc_set_paths: out of host memory");
+    memcpy(ctx->h_cx, cx, sizeof(double) * N); memcpy(ctx->h_cy, cy, sizeof(double) * N); memcpy(ctx->h_cyaw, cyaw, sizeof(double) * N);
+    if (ctx->have_geom) return upload_circle_centres(ctx);
     return 0;
 }
 
@@ -1316,6 +1351,58 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     else
         hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_set_geometry: null ctx");
+    if (!(radius > 0)) return fail(ctx, -22, "jsim_loop_set_geometry: radius must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->cc0 = cc_front; ctx->cc1 = cc_rear; ctx->col_radius = radius; ctx->have_geom = 1;
+    if (!ctx->d_pred_cc) HIP_TRY(ctx, hipMalloc(&ctx->d_pred_cc, sizeof(double2) * JSIM_MAX_OBS * JSIM_MAX_PRED * 2));
+    return upload_circle_centres(ctx);
+}
+
+extern "C" int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const double *obst, int32_t n_steps, double *pred,
+                                           void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_predict_obstacles: null ctx");
+    if (!ctx->have_geom) return fail(ctx, -22, "jsim_loop_predict_obstacles: jsim_loop_set_geometry has not been called");
+    if (n_obs < 0 || n_obs > JSIM_MAX_OBS || n_steps < 1 || n_steps > JSIM_MAX_PRED)
+        return fail(ctx, -22, "jsim_loop_predict_obstacles: n_obs=%d (max %d), n_steps=%d (max %d)", n_obs, JSIM_MAX_OBS, n_steps, JSIM_MAX_PRED);
+    ctx->pred_n_obs = n_obs; ctx->pred_n_steps = n_steps;
+    if (n_obs == 0) return 0;
+    if (!obst || !pred) return fail(ctx, -22, "jsim_loop_predict_obstacles: null device pointer");
+    ObsP P = {n_obs, n_steps, ctx->cfg.dt, ctx->cfg.L, ctx->cc0, ctx->cc1, obst, pred, ctx->d_pred_cc};
+    hipLaunchKernelGGL(obstacle_predict_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, int64_t *traj_idx,
+                                  const int32_t *prev_path_len, int32_t *path_len, int32_t *col_flag, double *col_xy,
+                                  int32_t *first_idx, int32_t *status, int32_t frame_window, int32_t margin,
+                                  int32_t *dbg_res_idx, int32_t *dbg_n_res, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_pre_tick: null ctx");
+    if (B < 0 || frame_window < 0 || frame_window > 32 || margin < 0) return fail(ctx, -22, "jsim_loop_pre_tick: bad argument");
+    if (B == 0) return 0;
+    if (!x0 || !path_id || !traj_idx || !prev_path_len || !path_len || !col_flag || !status)
+        return fail(ctx, -22, "jsim_loop_pre_tick: null device pointer");
+    if (!ctx->d_pxy || !ctx->d_pcc) return fail(ctx, -22, "jsim_loop_pre_tick: paths / geometry not set");
+    if (dbg_res_idx && !dbg_n_res) return fail(ctx, -22, "jsim_loop_pre_tick: dbg_res_idx needs dbg_n_res");
+    const jsim_cfg &c = ctx->cfg;
+    PreP P;
+    memset(&P, 0, sizeof(P));
+    P.B = B; P.n_obs = ctx->pred_n_obs; P.n_steps = ctx->pred_n_steps; P.frame_window = frame_window; P.margin = margin;
+    P.dt = c.dt; P.max_accel = c.max_accel; P.max_speed = c.max_speed; P.thr = 2.0 * ctx->col_radius;
+    P.pxy = ctx->d_pxy; P.pcc = ctx->d_pcc; P.poff = ctx->d_poff; P.pred_cc = ctx->d_pred_cc;
+    P.x0 = x0; P.path_id = path_id; P.traj_idx = (long long *)traj_idx; P.prev_path_len = prev_path_len; P.path_len = path_len;
+    P.col_flag = col_flag; P.col_xy = col_xy; P.first_idx = first_idx; P.status = status;
+    P.dbg_res_idx = dbg_res_idx; P.dbg_n_res = dbg_n_res;
+    hipLaunchKernelGGL(loop_pre_tick_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, P);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -115,6 +115,27 @@ int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *oa, double *
                       const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age,
                       double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream);
 
+/* ---- the loop glue that produces the truncated path, main/scenarios/mpc_intersection.py:104-140 ----
+ * jsim_loop_set_geometry: the car's two collision circles (offsets of their centres from the rear axle along the body
+ *   axis, radius) = car_dimensions.circle_centers / .radius, main/lib/car_dimensions.py:62-79; precomputes the circle
+ *   centres of every path point (main/lib/trajectories.py:11-55).  Call after jsim_mpc_set_paths or before; either order.
+ * jsim_loop_predict_obstacles: MovingObstaclesPrediction.state_prediction for n_obs obstacles (<= 8), n_steps samples
+ *   (<= 64; the loop uses len(arange(0, 7.0, DT)) = 35), main/lib/moving_obstacles_prediction.py:21-47.
+ *   obst [n_obs][6] = (x, y, v, yaw, a, steer) as MovingObstacle*.get() returns them; pred [n_obs][n_steps][3] = (x, y, yaw).
+ * jsim_loop_pre_tick: per ego -- progress index traj_idx on the FULL path (in/out; skipped when it sits on the last point
+ *   of the previous truncated path, :106-109), resample_curve of the remaining path with the accelerate-to-MAX_SPEED
+ *   spacing (:111-120, main/lib/trajectories.py:58-86), check_collision_moving_cars against the predictions with
+ *   +-frame_window frame offsets (main/lib/collision_avoidance.py:68-124), get_cutoff_curve_by_position_idx minus `margin`
+ *   (:133-140, main/lib/collision_avoidance.py:168-180).  path_len [B] out = cut-off length (full length if no collision) --
+ *   exactly what jsim_mpc_step takes.  prev_path_len [B]: previous tick's path_len, -1 before the first tick.
+ *   status: 0 ok, 2 nearest-index anomaly, 4 resampled path longer than the kernel's 320-point table. */
+int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius);
+int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const double *obst, int32_t n_steps, double *pred, void *stream);
+int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, int64_t *traj_idx,
+                       const int32_t *prev_path_len, int32_t *path_len, int32_t *col_flag, double *col_xy,
+                       int32_t *first_idx, int32_t *status, int32_t frame_window, int32_t margin,
+                       int32_t *dbg_res_idx /*[B][320]*/, int32_t *dbg_n_res, void *stream);
+
 /* n_ticks consecutive closed-loop ticks, each = jsim_mpc_step followed by jsim_loop_advance, with identical results.
  * For the horizons that have the fused register-resident kernel (T = 13, 20) this is ONE launch in which every
  * wavefront runs all n_ticks for its own ego (egos are independent, so none waits for the slowest solve of a tick);

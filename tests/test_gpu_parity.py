@@ -331,3 +331,71 @@ def test_lds_kernel_and_register_kernel_agree(pkg, oracle, routes, T, monkeypatc
         assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-8
     assert float((e_reg.oa - e_lds.oa).abs().max()) <= 1e-8
     assert torch.equal(e_reg.xref, e_lds.xref)
+
+
+def test_pre_tick_vs_reference_golden(pkg, routes):
+    """Row f1: resampled ego path, obstacle prediction, first collision, cut-off on the GPU against what the reference's
+    resample_curve / state_prediction / check_collision_moving_cars / get_cutoff_curve_by_position_idx returned."""
+    g = load_golden("loop_f1.npz")
+    n = len(g["route"])
+    eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=float(g["dl"]), T=13, smooth=False)
+    pre = pkg.PreTick(eng)
+    assert pre.margin == int(g["margin"]) and pre.n_steps == g["pred"].shape[2] and pre.radius == float(g["radius"])
+    dbg = {"res_idx": torch.zeros(1, 320, dtype=torch.int32, device=eng.device),
+           "n_res": torch.zeros(1, dtype=torch.int32, device=eng.device)}
+    x0 = torch.zeros(1, 4, dtype=torch.float64, device=eng.device)
+    n_col = 0
+    for k in range(n):
+        rid, idx, v = int(g["route"][k]), int(g["idx"][k]), float(g["v"][k])
+        eng.path_id.fill_(rid)
+        full = routes[rid]
+        # put the ego ON the path point idx and pin the progress index there (the golden case starts from idx)
+        x0[0, 0], x0[0, 1], x0[0, 2], x0[0, 3] = full[idx, 0], full[idx, 1], v, full[idx, 2]
+        pre.traj_idx.fill_(idx)
+        pre.prev_len.fill_(idx + 1)          # "progress index sits on the last point of the previous path" -> not updated
+        pred = pre.predict(torch.from_numpy(np.ascontiguousarray(g["obst"][k])).to(eng.device))
+        pre.run(x0, debug=dbg)
+        torch.cuda.synchronize()
+        assert int(pre.status.item()) == 0 and int(pre.traj_idx.item()) == idx
+        np.testing.assert_allclose(pred.cpu().numpy(), g["pred"][k], rtol=0, atol=1e-12)
+        nr = int(dbg["n_res"].item())
+        assert nr == int(g["n_res"][k])
+        assert np.array_equal(dbg["res_idx"][0, :nr].cpu().numpy(), g["res_idx"][k][:nr])
+        flag, cx, cy, first = g["col"][k]
+        assert int(pre.col_flag.item()) == int(flag)
+        assert int(eng.path_len.item()) == int(g["cutoff"][k])
+        if flag:
+            n_col += 1
+            assert int(pre.first_idx.item()) == int(first)
+            assert tuple(pre.col_xy[0].cpu().numpy()) == (cx, cy)
+    assert n_col >= 100
+
+
+def test_closed_loop_config1_replay(pkg, routes):
+    """Config 1 (mpc_intersection, 1 ego, stock T = 13): every tick of the recorded reference loop replayed through the GPU
+    loop glue + MPC step: progress index, cut-off and target_ind bit-exact, controls within 1e-7 of the recorded ones."""
+    g = load_golden("loop_closed_T13.npz")
+    full = routes[int(g["route_id"])]
+    dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+    eng = pkg.BatchedMPC([full.copy()], [0], dl=dl, T=13, smooth=False)
+    pre = pkg.PreTick(eng)
+    x0 = torch.zeros(1, 4, dtype=torch.float64, device=eng.device)
+    n_cut = 0
+    for row in g["ticks"]:
+        x, y, yaw, v, idx_in, prev_len, idx_out, plen, hit, tind_in, tind_out, status, delta, accel, dev = row[:15]
+        obst = np.ascontiguousarray(row[15:].reshape(-1, 6))
+        x0[0, 0], x0[0, 1], x0[0, 2], x0[0, 3] = x, y, v, yaw
+        pre.traj_idx.fill_(int(idx_in)); pre.prev_len.fill_(int(prev_len))
+        pre.predict(torch.from_numpy(obst).to(eng.device))
+        pre.run(x0)
+        eng.target_ind.fill_(int(tind_in))
+        di, ai = eng.step(x0)
+        torch.cuda.synchronize()
+        assert int(pre.traj_idx.item()) == int(idx_out)
+        assert int(eng.path_len.item()) == int(plen) and int(pre.col_flag.item()) == int(hit)
+        assert int(eng.status.item()) == int(status) and int(eng.target_ind.item()) == int(tind_out)
+        assert abs(float(di) - delta) <= 1e-7 and abs(float(ai) - accel) <= 1e-7
+        devs, _ = eng.xref_deviation_and_goal(x0)
+        assert abs(float(devs) - dev) <= 1e-7
+        n_cut += int(hit)
+    assert n_cut >= 20

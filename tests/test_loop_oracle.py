@@ -1,0 +1,74 @@
+"""Row f1 of SURVEY.md 8 -- the loop glue that produces the truncated path: the numpy oracle (oracle/loop_oracle.py)
+against golden vectors made by the reference's own resample_curve / state_prediction / check_collision_moving_cars /
+get_cutoff_curve_by_position_idx, and against the recorded closed loop of config 1.  CPU only.
+Bars: every index (kept points, hit index, cut-off, progress index, path_len) bit-exact; predictions <= 1e-12."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+@pytest.fixture(scope="module")
+def LO(oracle):
+    import loop_oracle
+    return loop_oracle
+
+
+def test_car_circles_match_reference(LO):
+    g = load_golden("loop_f1.npz")
+    radius, offs = LO.car_circles()
+    assert radius == float(g["radius"])
+    assert np.array_equal(np.array([[offs[0], 0.0], [offs[1], 0.0]]), g["circle_centers"])
+    assert LO.extra_cutoff_margin(float(g["dl"])) == int(g["margin"])
+
+
+def test_resample_prediction_collision_cutoff(LO, routes):
+    g = load_golden("loop_f1.npz")
+    n_col = 0
+    for k in range(len(g["route"])):
+        full = routes[int(g["route"][k])]
+        idx, v = int(g["idx"][k]), float(g["v"][k])
+        detailed = full[idx:]
+        mask = LO.resample_mask(detailed[:, :2], LO.ego_resample_dl(len(detailed), v))
+        keep = np.flatnonzero(mask)
+        assert np.array_equal(keep, g["res_idx"][k][: int(g["n_res"][k])])
+        preds = [LO.predict_obstacle(*o) for o in g["obst"][k]]
+        np.testing.assert_allclose(np.stack(preds), g["pred"][k], rtol=0, atol=1e-12)
+        preds = list(g["pred"][k])      # continue from the reference's predictions: indices must then be identical
+        res = detailed[mask]
+        col = LO.first_collision_fast(res, detailed, preds)
+        flag, cx, cy, first = g["col"][k]
+        if flag == 0:
+            assert col is None
+            continue
+        n_col += 1
+        assert col is not None and col[2] == int(first) and col[0] == cx and col[1] == cy
+        if k % 8 == 0:   # the explicit-loop form agrees with the vectorised one
+            assert LO.first_collision(res, detailed, preds) == col
+        c = LO.cutoff_index(full, col[0], col[1])
+        assert max(idx + 1, c - int(g["margin"])) == int(g["cutoff"][k])
+    assert n_col >= 100
+
+
+def test_closed_loop_pre_tick_matches_reference_loop(LO, routes):
+    """Every tick of the recorded mpc_intersection loop: progress index, cut-off / path_len from the oracle's loop glue;
+    controls from the oracle MPC on the same inputs."""
+    g = load_golden("loop_closed_T13.npz")
+    import oracle_py as O
+    full = routes[int(g["route_id"])]
+    p = O.make_params(T=13, dl=float(np.linalg.norm(full[0, :2] - full[1, :2])))
+    oa = od = None
+    n_cut = 0
+    for row in g["ticks"]:
+        x, y, yaw, v, idx_in, prev_len, idx_out, plen, hit, tind_in, tind_out, status, delta, accel, dev = row[:15]
+        obst = row[15:].reshape(-1, 6)
+        st, idx, path_len, col = LO.loop_pre_tick((x, y, yaw, v), int(idx_in), None if prev_len < 0 else int(prev_len),
+                                                   full, obst, p.dl)
+        assert st == 0 and idx == int(idx_out) and path_len == int(plen) and (col is not None) == bool(hit)
+        n_cut += bool(hit)
+        tr = full[:path_len]
+        r = O.mpc_step(p, (x, y, yaw, v), tr[:, 0], tr[:, 1], tr[:, 2], int(tind_in), 30 / 3.6, oa=oa, od=od)
+        assert r["status"] == int(status) and r["target_ind"] == int(tind_out)
+        assert abs(r["od"][0] - delta) <= 1e-12 and abs(r["oa"][0] - accel) <= 1e-12
+        oa, od = r["oa"], r["od"]
+    assert n_cut >= 20 and bool(g["reached_goal"])
