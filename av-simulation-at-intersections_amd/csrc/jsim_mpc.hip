@@ -15,7 +15,7 @@
 //                             matrix cores (v_mfma_f64_16x16x4_f64, K = the 4 state components of one time
 //                             step), block-triangular zero tiles skipped; g, R, Rd terms on the VALU
 //                             reference: main/lib/mpc.py:141-186 (cost), :176-178,189 (dynamics eliminated)
-//   S4b exact QP solve        Goldfarb-Idnani dual active set; H -> L (Cholesky) -> J = L^-T and the working
+//   S4b exact QP solve        Goldfarb-Idnani dual active set (entering row: largest viol^2 / n'H^-1 n); H -> L (Cholesky) -> J = L^-T and the working
 //                             set's R factor live in LDS (lane i owns row i); constraints are evaluated from
 //                             their structure (boxes, steer-rate differences, speed = prefix sums of accel)
 //                             reference: main/lib/mpc.py:187-199 (constraints; cvxpy->ECOS solve replaced)
@@ -575,11 +575,42 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
 
     STAMP(9);
     // ------------------------------------------------------------------ Goldfarb-Idnani dual active-set iterations
+    // static steepest-edge weights of the entering-row rule, per time lane t: 1 / ||J'n||^2 for the rate rows
+    // (J[2t+3] - J[2t+1]), the speed rows (dt * sum_{s<t} J[2s]), the accel rows (J[2t]) and the steer rows (J[2t+1]).
+    // Rm (L is dead, R not yet started) is the scratch for the cumulative accel rows.
+    double iwD = 1.0, iwV = 1.0, iwA = 1.0, iwS = 1.0;
+    {
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int j = lane + 64 * rr;
+            if (j < n) {
+                double c = 0.0;
+                for (int ss = 0; ss < T; ++ss) { c += Jm[(2 * ss) * ld + j]; Rm[(ss + 1) * ld + j] = c; }
+            }
+        }
+        LDS_SYNC();
+        const int t = lane;
+        if (t <= T) {
+            double wD = 0.0, wV = 0.0, wA = 0.0, wS = 0.0;
+            for (int j = 0; j < n; ++j) {
+                if (t >= 1) { const double c = Rm[t * ld + j]; wV = fma(c, c, wV); }
+                if (t < T) {
+                    const double ja = Jm[(2 * t) * ld + j], js = Jm[(2 * t + 1) * ld + j];
+                    wA = fma(ja, ja, wA); wS = fma(js, js, wS);
+                    if (t + 1 < T) { const double e = Jm[(2 * t + 3) * ld + j] - js; wD = fma(e, e, wD); }
+                }
+            }
+            wV *= dt * dt;
+            iwD = 1.0 / (wD > 0.0 ? wD : 1.0); iwV = 1.0 / (wV > 0.0 ? wV : 1.0);
+            iwA = 1.0 / (wA > 0.0 ? wA : 1.0); iwS = 1.0 / (wS > 0.0 ? wS : 1.0);
+        }
+        LDS_SYNC();
+    }
     int q = 0, iters = 0;
     const int max_iters = 50 * n + 100;
     unsigned abits = 0; // lane t: which of the 8 rows of time step t are in the working set
     for (;;) {
-        // ---- step 1: most violated row (ties -> lowest canonical index)
+        // ---- step 1: among the violated rows the one with the largest viol^2 / (n'H^-1 n) (ties -> lowest canonical index)
         int p;
         double violp;
         {
@@ -587,26 +618,29 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
             double a = 0.0, dl_ = 0.0, dnext = 0.0;
             if (t < T) { double2 ad = *(const double2 *)&uvec[2 * t]; a = ad.x; dl_ = ad.y; dnext = uvec[2 * t + 3]; }
             const double vt = sv + dt * wexscan(a, lane);
-            double best = 0.0;
+            double best = 0.0, bviol = 0.0;
             int bid = 0x7fffffff;
-#define CONSIDER(valid, bit, viol_expr, habs, id_expr)                                   \
+#define CONSIDER(valid, bit, viol_expr, habs, id_expr, iw)                               \
     if ((valid) && !(abits & (1u << (bit)))) {                                           \
         const double vv = (viol_expr);                                                   \
         const int id_ = (id_expr);                                                       \
-        if (vv > JSIM_VIOL_TOL * (1.0 + (habs)) && (vv > best || (vv == best && id_ < bid))) { best = vv; bid = id_; } \
+        const double key_ = vv * vv * (iw);                                              \
+        if (vv > JSIM_VIOL_TOL * (1.0 + (habs)) && (key_ > best || (key_ == best && id_ < bid))) { best = key_; bid = id_; bviol = vv; } \
     }
-            CONSIDER(t + 1 < T, 0, (dnext - dl_) - P.dmax, P.dmax, 2 * t)
-            CONSIDER(t + 1 < T, 1, (dl_ - dnext) - P.dmax, P.dmax, 2 * t + 1)
-            CONSIDER(t >= 1 && t <= T, 2, vt - speed, fabs(speed - sv), 2 * T - 2 + t)
-            CONSIDER(t >= 1 && t <= T, 3, P.vmin - vt, fabs(sv - P.vmin), 3 * T - 1 + t)
-            CONSIDER(t < T, 4, a - P.amax, fabs(P.amax), 4 * T + t)
-            CONSIDER(t < T, 5, P.amin - a, fabs(P.amin), 5 * T + t)
-            CONSIDER(t < T, 6, dl_ - P.smax, P.smax, 6 * T + 2 * t)
-            CONSIDER(t < T, 7, -dl_ - P.smax, P.smax, 6 * T + 2 * t + 1)
+            CONSIDER(t + 1 < T, 0, (dnext - dl_) - P.dmax, P.dmax, 2 * t, iwD)
+            CONSIDER(t + 1 < T, 1, (dl_ - dnext) - P.dmax, P.dmax, 2 * t + 1, iwD)
+            CONSIDER(t >= 1 && t <= T, 2, vt - speed, fabs(speed - sv), 2 * T - 2 + t, iwV)
+            CONSIDER(t >= 1 && t <= T, 3, P.vmin - vt, fabs(sv - P.vmin), 3 * T - 1 + t, iwV)
+            CONSIDER(t < T, 4, a - P.amax, fabs(P.amax), 4 * T + t, iwA)
+            CONSIDER(t < T, 5, P.amin - a, fabs(P.amin), 5 * T + t, iwA)
+            CONSIDER(t < T, 6, dl_ - P.smax, P.smax, 6 * T + 2 * t, iwS)
+            CONSIDER(t < T, 7, -dl_ - P.smax, P.smax, 6 * T + 2 * t + 1, iwS)
 #undef CONSIDER
+            const int mybid = bid;
             wargmax(best, bid);
             p = uni(bid);
-            violp = uni(best);
+            // the violation of the winner: held by the one lane whose candidate won
+            violp = uni(wsum(mybid == p && p != 0x7fffffff ? bviol : 0.0));
         }
         if (p == 0x7fffffff) break; // optimal
 
