@@ -425,11 +425,14 @@ int orc_solve_qp(int n, int m, const double *H, const double *g, const double *G
     for (int i = 0; i < m; ++i) {
         double acc = 0.0;
         if (!skip[i]) {
-            for (int j = 0; j < n; ++j) {
-                double dj = 0.0;
-                for (int c = 0; c < n; ++c) dj += G[i * n + c] * J[c * n + j];
-                acc += dj * dj;
+            /* rows of G are sparse (1, 2 or t non-zeros): accumulate G_i J over the non-zero columns only */
+            for (int j = 0; j < n; ++j) d[j] = 0.0;
+            for (int c = 0; c < n; ++c) {
+                const double gc = G[i * n + c];
+                if (gc != 0.0)
+                    for (int j = c; j < n; ++j) d[j] += gc * J[c * n + j]; /* J = L^-T is upper triangular here */
             }
+            for (int j = 0; j < n; ++j) acc += d[j] * d[j];
         }
         wgt[i] = acc > 0.0 ? acc : 1.0;
     }
