@@ -399,3 +399,52 @@ def test_closed_loop_config1_replay(pkg, routes):
         assert abs(float(devs) - dev) <= 1e-7
         n_cut += int(hit)
     assert n_cut >= 20
+
+
+@pytest.mark.parametrize("T", (1, 2, 3, 5, 8, 16, 21, 24, 32, 48))
+def test_generic_kernel_any_horizon(pkg, oracle, routes, T):
+    """Horizons without a register kernel go through the generic LDS-resident kernel: tiny horizons (n < one MFMA tile),
+    n an exact multiple of the 16-column tile (T = 8, 16, 24, 32, 48), the largest supported T, two rows per lane (T > 32)."""
+    B = 48
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=100 + T, truncate=True, near_end_frac=0.3)
+    eng = _engine(pkg, routes, batch, T)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+    torch.cuda.synchronize()
+    p, ref = _oracle_batch(oracle, pkg, routes, batch, T)
+    assert np.array_equal(eng.status.cpu().numpy(), ref["status"])
+    assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy(), ref["xref"])
+    ok = ref["status"] == 0
+    assert ok.sum() >= B - 4
+    tol = 1e-8 if T <= 32 else 1e-6
+    assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= tol
+    assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= tol
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
+
+
+def test_degenerate_paths_and_positions(pkg, oracle):
+    """Paths of 1, 2, 3 and 4 points, egos beyond the path end, a remembered index past a truncated path (the reference's
+    empty-tail case) -- every index and status must match the oracle (which is pinned on these cases by the reference)."""
+    T = 13
+    base = pkg.synth.make_route(1, 2)
+    pkg.synth.smooth_yaw_inplace(base[:, 2])
+    paths = [base[:1].copy(), base[:2].copy(), base[:3].copy(), base[:4].copy(), base.copy()]
+    pid = np.array([0, 1, 2, 3, 4, 4, 4, 4], dtype=np.int32)
+    B = len(pid)
+    x0 = np.zeros((B, 4)); x0[:, 0] = 3.0; x0[:, 1] = -30.0 + np.arange(B) * 0.05; x0[:, 2] = 2.0; x0[:, 3] = np.pi / 2
+    x0[5, 1] = 40.0                       # beyond the end of the path
+    tind = np.zeros(B, dtype=np.int64); tind[6] = 700; tind[7] = 719
+    plen = np.array([1, 2, 3, 4, 720, 720, 650, 720], dtype=np.int32)   # ego 6: index past the truncated path
+    eng = pkg.BatchedMPC(paths, pid, dl=pkg.synth.DL, T=T, smooth=False)
+    eng.load_state(tind, np.zeros((B, T)), np.zeros((B, T)), plen)
+    eng.solve(torch.from_numpy(x0).to(eng.device))
+    torch.cuda.synchronize()
+    p = oracle.make_params(T=T)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(paths)
+    ref = oracle.mpc_step_batch(p, x0, pid, plen, np.full(B, 30 / 3.6), cx, cy, cyaw, off, tind, np.zeros((B, T)), np.zeros((B, T)))
+    assert np.array_equal(eng.status.cpu().numpy(), ref["status"])
+    assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy(), ref["xref"])
+    ok = ref["status"] == 0
+    assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-8
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
