@@ -33,7 +33,8 @@ class BatchedMPC:
     def __init__(self, paths: Sequence[np.ndarray], path_id: Union[np.ndarray, Sequence[int]], dl: float,
                  L: float = 2.86, speed: Union[float, np.ndarray] = 30 / 3.6, dt: float = 0.2,
                  T: Optional[int] = None, config: Optional[MPCConfig] = None,
-                 device: Union[str, torch.device] = "cuda:0", smooth: bool = True):
+                 device: Union[str, torch.device] = "cuda:0", smooth: bool = True,
+                 cv: Optional[Sequence[np.ndarray]] = None):
         self.lib = _cabi.load()  # raises if the HIP library is missing: no fallback
         if not torch.cuda.is_available():
             raise _cabi.JsimError("BatchedMPC needs a HIP device (torch.cuda.is_available() is False); "
@@ -56,6 +57,14 @@ class BatchedMPC:
         self._ctx = C.c_void_p()
         _cabi.check(self.lib.jsim_mpc_create(C.byref(cfg), self.dev_index, C.byref(self._ctx)), None, "jsim_mpc_create")
         self._upload_paths()
+        # mpc_with_speed variant: per-point speed reference (one array per path), xref[2] = cv[idx]
+        self.cv = None if cv is None else [np.ascontiguousarray(c, dtype=np.float64) for c in cv]
+        self.cv_cut = None
+        if self.cv is not None:
+            if len(self.cv) != len(self.paths) or any(len(c) != len(p) for c, p in zip(self.cv, self.paths)):
+                raise ValueError("cv must hold one speed array per path, of the path's length")
+            flat = np.concatenate(self.cv)
+            _cabi.check(self.lib.jsim_mpc_set_path_speed(self._ctx, flat.ctypes.data), self._ctx, "jsim_mpc_set_path_speed")
 
         pid = np.ascontiguousarray(path_id, dtype=np.int32)
         if pid.ndim != 1 or (pid.size and (pid.min() < 0 or pid.max() >= len(self.paths))):
@@ -102,6 +111,26 @@ class BatchedMPC:
         if bool((pl < 1).any()) or bool((pl > self.full_len).any()):
             raise ValueError("path_len must satisfy 1 <= path_len[b] <= len(paths[path_id[b]])")
         self.path_len = pl.contiguous()
+
+    def set_speed_cutoff(self, cutoff: Optional[Union[np.ndarray, torch.Tensor]]):
+        """Batched `set_trajectory_fromarray(trajectory, cutoff_idx)` of the mpc_with_speed variant
+        (main/lib/mpc_with_speed.py:276-282): ego b's speed reference is 0 from path index cutoff[b] on (< 0: nowhere)."""
+        if cutoff is None:
+            self.cv_cut = None
+            _cabi.check(self.lib.jsim_mpc_set_speed_cutoff(self._ctx, None), self._ctx, "jsim_mpc_set_speed_cutoff")
+            return
+        t = cutoff if isinstance(cutoff, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(cutoff, dtype=np.int32))
+        self.cv_cut = t.to(device=self.device, dtype=torch.int32).contiguous()
+        if self.cv_cut.shape != (self.B,):
+            raise ValueError("cutoff must have shape [B]")
+        _cabi.check(self.lib.jsim_mpc_set_speed_cutoff(self._ctx, _ptr(self.cv_cut)), self._ctx, "jsim_mpc_set_speed_cutoff")
+
+    def update_config(self, config: MPCConfig):
+        """New weights / limits for the following solves (what main/lib/mpc_sensitivity.py does by re-reading its JSON in
+        every solve, :153-166).  The horizon cannot change."""
+        cfg = _cabi.make_cfg(config, self.T, self.dt, self.dl, self.L)
+        _cabi.check(self.lib.jsim_mpc_update_cfg(self._ctx, C.byref(cfg)), self._ctx, "jsim_mpc_update_cfg")
+        self.config, self._cfg = config, cfg
 
     def load_state(self, target_ind=None, oa=None, od=None, path_len=None):
         """Overwrite the resident controller state (host arrays or tensors): remembered path index, warm

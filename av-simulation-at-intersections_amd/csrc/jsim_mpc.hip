@@ -48,6 +48,8 @@ struct KP {
     double dmax, amax, amin, smax, vmax_plant, vmin, vref_min;
     const double2 *pxy;
     const double *pyaw;
+    const double *pcv;   // per-point speed reference of the mpc_with_speed variant, or NULL (xref[2] = 0, mpc.py:107)
+    const int *cv_cut;   // [B] index from which that reference is zeroed, or NULL
     const long long *poff;
     const double *x0;
     const int *path_id;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     STAMP(1);
     // ------------------------------------------------------------------ S1: travel -> idx -> xref
     const int tl_idx = lane < T ? lane : T; // lanes > T mirror lane T (keeps loads in range)
-    double xr, yr, yawr;
+    double xr, yr, yawr, vr = 0.0;
     bool rend;
     long long ik;
     {
@@ -251,6 +253,10 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
         double2 pr = P.pxy[off + ik];
         xr = pr.x; yr = pr.y; yawr = P.pyaw[off + ik];
         rend = (ik == M - 1);
+        if (P.pcv) { // mpc_with_speed variant: xref[2] = cv[idx], cv zeroed from the ego's cut-off index on
+            const int cut = P.cv_cut ? P.cv_cut[ego] : -1;
+            vr = (cut < 0 || ik < cut) ? P.pcv[off + ik] : 0.0;
+        }
     }
 
     // infeasible constant rows x[2,0] <= speed, x[2,0] >= MIN_SPEED (ECOS feasibility tolerance)
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     if (P.xref && lane <= T) {
         double *xf = P.xref + (size_t)ego * 4 * (T + 1);
         xf[0 * (T + 1) + lane] = xr; xf[1 * (T + 1) + lane] = yr;
-        xf[2 * (T + 1) + lane] = 0.0; xf[3 * (T + 1) + lane] = yawr;
+        xf[2 * (T + 1) + lane] = vr; xf[3 * (T + 1) + lane] = yawr;
     }
     if (status == JSIM_INFEASIBLE) {
         // reference: solver reports infeasible -> None outputs; target_ind/xref are still stored (mpc.py:293)
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
                 Qxx = P.Qf0; Qyy = P.Qf1; qv = P.Qf2; qyaw = P.Qf3;
             }
         }
-        double ex = FX - xr, ey = FY - yr, ev = sv, eyaw = syaw - yawr;
+        double ex = FX - xr, ey = FY - yr, ev = sv - vr, eyaw = syaw - yawr;
         if (lane <= T + 1) {
             const int t = lane;
             bool in = lane <= T;
@@ -1064,6 +1070,8 @@ struct jsim_ctx {
     double2 *d_pcc;
     double2 *d_pred_cc;
     int pred_n_obs, pred_n_steps;
+    double *d_pcv;          // speed reference per path point (mpc_with_speed variant) or NULL
+    const int *cv_cut;      // caller-owned device array [B] or NULL
     size_t lds_bytes;
     int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
     int dbg_max_gi;
@@ -1137,6 +1145,8 @@ static void free_paths(jsim_ctx *c)
     if (c->d_pyaw) (void)hipFree(c->d_pyaw);
     if (c->d_poff) (void)hipFree(c->d_poff);
     if (c->d_pcc) (void)hipFree(c->d_pcc);
+    if (c->d_pcv) (void)hipFree(c->d_pcv);
+    c->d_pcv = nullptr;
     delete[] c->h_cx; delete[] c->h_cy; delete[] c->h_cyaw;
     c->h_cx = c->h_cy = c->h_cyaw = nullptr; c->d_pcc = nullptr;
     c->d_pxy = nullptr; c->d_pyaw = nullptr; c->d_poff = nullptr;
@@ -1214,6 +1224,7 @@ static void fill_kp(const jsim_ctx *ctx, int32_t B, KP &P)
     P.dmax = c.max_dsteer * c.dt; P.amax = c.max_accel; P.amin = c.max_decel; P.smax = c.max_steer;
     P.vmax_plant = c.max_speed; P.vmin = c.min_speed; P.vref_min = c.min_ref_speed;
     P.pxy = ctx->d_pxy; P.pyaw = ctx->d_pyaw; P.poff = ctx->d_poff;
+    P.pcv = ctx->d_pcv; P.cv_cut = ctx->cv_cut;
 }
 
 static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, const int32_t *path_len,
@@ -1438,5 +1449,37 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
     P.dbg_res_idx = dbg_res_idx; P.dbg_n_res = dbg_n_res;
     hipLaunchKernelGGL(loop_pre_tick_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, P);
     HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- MPC variants of the reference that differ from main/lib/mpc.py only in data ----
+extern "C" int jsim_mpc_set_path_speed(jsim_ctx *ctx, const double *cv)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_path_speed: null ctx");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_pcv) { (void)hipFree(ctx->d_pcv); ctx->d_pcv = nullptr; }
+    if (!cv) return 0; // back to the plain controller (no speed reference)
+    if (ctx->n_points <= 0) return fail(ctx, -22, "jsim_mpc_set_path_speed: call jsim_mpc_set_paths first");
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pcv, sizeof(double) * ctx->n_points));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_pcv, cv, sizeof(double) * ctx->n_points, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int jsim_mpc_set_speed_cutoff(jsim_ctx *ctx, const int32_t *cv_cut)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_speed_cutoff: null ctx");
+    ctx->cv_cut = cv_cut;
+    return 0;
+}
+
+extern "C" int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg)
+{
+    if (!ctx || !cfg) return fail(ctx, -22, "jsim_mpc_update_cfg: null argument");
+    if (cfg->T != ctx->cfg.T) return fail(ctx, -22, "jsim_mpc_update_cfg: the horizon cannot change (T=%d -> %d)", ctx->cfg.T, cfg->T);
+    if (cfg->max_iter != 1) return fail(ctx, -22, "jsim_mpc_update_cfg: MAX_ITER=%d unsupported", cfg->max_iter);
+    if (!(cfg->dt > 0) || !(cfg->dl > 0) || !(cfg->L > 0) || !(cfg->R[0] > 0) || !(cfg->R[1] > 0) || !(cfg->R_end[0] > 0) ||
+        !(cfg->R_end[1] > 0))
+        return fail(ctx, -22, "jsim_mpc_update_cfg: dt, dl, L, R, R_end must be positive");
+    ctx->cfg = *cfg;
     return 0;
 }

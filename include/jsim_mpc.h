@@ -16,6 +16,8 @@
  *   jsim_loop_advance    <- the rest of the loop body: plant update, history, `if mpc.is_goal(state): break`
  *                           main/scenarios/mpc_intersection.py:99-101,163 ; main/lib/simulation.py:64-88 (History)
  *   jsim_mpc_run_ticks   <- `for i in itertools.count():` itself, main/scenarios/mpc_intersection.py:99 (K iterations per call)
+ *   jsim_mpc_set_path_speed / _set_speed_cutoff / _update_cfg <- the data-only MPC variants main/lib/mpc_with_speed.py,
+ *                           main/lib/mpc_sensitivity.py
  *   jsim_mpc_xref_deviation_goal <- MPC.get_current_xref_deviation / MPC.is_goal  main/lib/mpc.py:305-330
  *
  * Conventions
@@ -114,6 +116,18 @@ int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *oa, double *
                       double *di_ai, int64_t *target_ind, const int32_t *path_id, const int32_t *path_len,
                       const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age,
                       double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream);
+
+/* ---- MPC variants that differ from main/lib/mpc.py only in data ----
+ * jsim_mpc_set_path_speed: per-point speed reference cv (HOST array aligned with cx/cy/cyaw of jsim_mpc_set_paths, or NULL
+ *   to switch it off): xref[2] = cv[idx] instead of 0, main/lib/mpc_with_speed.py:85-110.
+ * jsim_mpc_set_speed_cutoff: caller-owned DEVICE array [B] (or NULL): ego b's reference is zeroed from that path index on
+ *   (set_trajectory_fromarray(trajectory, cutoff_idx), main/lib/mpc_with_speed.py:276-282); entries < 0 mean no cut-off.
+ * jsim_mpc_update_cfg: replace weights / limits between solves (same T), which is what main/lib/mpc_sensitivity.py does by
+ *   re-reading its JSON inside every solve (:153-166).  The other differences of the variants are parameter values:
+ *   mpc_with_speed uses w_perp = 10, Q_v_yaw = (20, 0.5), MAX_DECEL = -5 and speed limit Simulation.MAX_SPEED. */
+int jsim_mpc_set_path_speed(jsim_ctx *ctx, const double *cv);
+int jsim_mpc_set_speed_cutoff(jsim_ctx *ctx, const int32_t *cv_cut);
+int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg);
 
 /* ---- the loop glue that produces the truncated path, main/scenarios/mpc_intersection.py:104-140 ----
  * jsim_loop_set_geometry: the car's two collision circles (offsets of their centres from the rear axle along the body

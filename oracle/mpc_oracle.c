@@ -96,7 +96,8 @@ int orc_nearest_index_in_direction(double x, double y, const double *cx, const d
  * ---------------------------------------------------------------------------------------------- */
 static int calc_ref_trajectory_impl(const orc_params *p, double sx, double sy, double sv,
                                     const double *ov_in, const double *cx, const double *cy,
-                                    const double *cyaw, int64_t ncourse, int64_t start_idx,
+                                    const double *cyaw, const double *cv, int64_t cv_cut,
+                                    int64_t ncourse, int64_t start_idx,
                                     double *xref, int64_t *idx, uint8_t *reaches_end,
                                     int64_t *target_ind)
 {
@@ -120,7 +121,9 @@ static int calc_ref_trajectory_impl(const orc_params *p, double sx, double sy, d
         idx[k] = ik;
         xref[0 * (T + 1) + k] = cx[ik];
         xref[1 * (T + 1) + k] = cy[ik];
-        xref[2 * (T + 1) + k] = 0.0;
+        /* mpc.py:107 leaves the speed reference at 0; the mpc_with_speed variant sets xref[2] = cv[idx]
+         * (mpc_with_speed.py:103-104) with cv zeroed from a cut-off index on (:276-282) */
+        xref[2 * (T + 1) + k] = (cv && (cv_cut < 0 || ik < cv_cut)) ? cv[ik] : 0.0;
         xref[3 * (T + 1) + k] = cyaw[ik];
         reaches_end[k] = (ik == ncourse - 1);
     }
@@ -131,7 +134,7 @@ int orc_calc_ref_trajectory(const orc_params *p, double sx, double sy, double sv
                             const double *cy, const double *cyaw, int64_t ncourse, int64_t start_idx,
                             double *xref, int64_t *idx, uint8_t *reaches_end, int64_t *target_ind)
 {
-    return calc_ref_trajectory_impl(p, sx, sy, sv, NULL, cx, cy, cyaw, ncourse, start_idx, xref, idx,
+    return calc_ref_trajectory_impl(p, sx, sy, sv, NULL, cx, cy, cyaw, NULL, -1, ncourse, start_idx, xref, idx,
                                     reaches_end, target_ind);
 }
 
@@ -585,6 +588,15 @@ int orc_mpc_step(const orc_params *p, double sx, double sy, double syaw, double 
                  const double *cy, const double *cyaw, int64_t ncourse, int64_t target_ind,
                  double speed, const double *oa_in, const double *od_in, orc_step_out *out)
 {
+    return orc_mpc_step_cv(p, sx, sy, syaw, sv, cx, cy, cyaw, NULL, -1, ncourse, target_ind, speed, oa_in, od_in, out);
+}
+
+/* the same step with a per-point speed reference cv (NULL: none) zeroed from index cv_cut on (< 0: nowhere):
+ * main/lib/mpc_with_speed.py:85-110,276-282 */
+int orc_mpc_step_cv(const orc_params *p, double sx, double sy, double syaw, double sv, const double *cx,
+                    const double *cy, const double *cyaw, const double *cv, int64_t cv_cut, int64_t ncourse,
+                    int64_t target_ind, double speed, const double *oa_in, const double *od_in, orc_step_out *out)
+{
     const int T = p->T, n = 2 * T, m = 8 * T, W = T + 1;
     double x0[4] = {sx, sy, sv, syaw}; /* mpc.py:291 */
     double *oa = (double *)calloc(T, sizeof(double));
@@ -614,7 +626,7 @@ int orc_mpc_step(const orc_params *p, double sx, double sy, double syaw, double 
     }
     int passes = p->max_iter > 0 ? p->max_iter : 1;
     for (int it = 0; it < passes; ++it) { /* mpc.py:231 */
-        status = calc_ref_trajectory_impl(p, sx, sy, sv, have_ov ? ovprev : NULL, cx, cy, cyaw, ncourse,
+        status = calc_ref_trajectory_impl(p, sx, sy, sv, have_ov ? ovprev : NULL, cx, cy, cyaw, cv, cv_cut, ncourse,
                                           tind, xref, idx, rend, &tind);
         if (status != ORC_OK) break;
         orc_predict_motion(p, x0, oa, od, xbar);
@@ -676,6 +688,17 @@ int orc_mpc_step_batch(const orc_params *p, int32_t B, const double *x0, const i
                        double *ov, double *oyaw, double *xref, uint32_t *active_mask,
                        int32_t *status, int32_t *n_iter, int32_t n_threads)
 {
+    return orc_mpc_step_batch_cv(p, B, x0, path_id, path_len, speed, cx, cy, cyaw, NULL, NULL, path_off, target_ind, oa,
+                                 od, ox, oy, ov, oyaw, xref, active_mask, status, n_iter, n_threads);
+}
+
+int orc_mpc_step_batch_cv(const orc_params *p, int32_t B, const double *x0, const int32_t *path_id,
+                          const int32_t *path_len, const double *speed, const double *cx,
+                          const double *cy, const double *cyaw, const double *cv, const int32_t *cv_cut,
+                          const int64_t *path_off, int64_t *target_ind, double *oa, double *od, double *ox,
+                          double *oy, double *ov, double *oyaw, double *xref, uint32_t *active_mask,
+                          int32_t *status, int32_t *n_iter, int32_t n_threads)
+{
     const int T = p->T, W = T + 1, MW = (8 * T + 31) / 32;
     (void)n_threads;
 #ifdef _OPENMP
@@ -694,9 +717,10 @@ int orc_mpc_step_batch(const orc_params *p, int32_t B, const double *x0, const i
         o.oyaw = o.ov + W;
         o.xref = o.oyaw + W;
         o.active_mask = active_mask ? &active_mask[(size_t)b * MW] : NULL;
-        int st = orc_mpc_step(p, x0[4 * b + 0], x0[4 * b + 1], x0[4 * b + 3], x0[4 * b + 2], cx + off,
-                              cy + off, cyaw + off, (int64_t)path_len[b], target_ind[b], speed[b],
-                              oa ? &oa[(size_t)b * T] : NULL, od ? &od[(size_t)b * T] : NULL, &o);
+        int st = orc_mpc_step_cv(p, x0[4 * b + 0], x0[4 * b + 1], x0[4 * b + 3], x0[4 * b + 2], cx + off,
+                                 cy + off, cyaw + off, cv ? cv + off : NULL, cv_cut ? (int64_t)cv_cut[b] : -1,
+                                 (int64_t)path_len[b], target_ind[b], speed[b],
+                                 oa ? &oa[(size_t)b * T] : NULL, od ? &od[(size_t)b * T] : NULL, &o);
         if (st != ORC_NEAREST_ANOMALY) target_ind[b] = o.target_ind;
         if (st == ORC_OK) {
             if (oa) memcpy(&oa[(size_t)b * T], o.oa, sizeof(double) * T);

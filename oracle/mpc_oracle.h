@@ -15,6 +15,8 @@
  *   main/lib/mpc.py:141-211   _linear_mpc_control   (QP build; the cvxpy->ECOS solve is replaced, see below)
  *   main/lib/mpc.py:214-242   _iterative_linear_mpc_control (MAX_ITER passes)
  *   main/lib/mpc.py:284-330   MPC.step / get_current_xref_deviation / is_goal
+ *   main/lib/mpc_with_speed.py:85-110,276-282  the variant's speed reference cv (orc_mpc_step_cv); its other
+ *                             differences are parameter values (weights, MAX_DECEL, speed limit)
  *   main/lib/trajectories.py:100-126  calc_nearest_index_in_direction
  *   main/lib/simulation.py:22-47      Simulation.step (plant, clamps)
  *   main/bicycle/main.py:28-41        Bicycle.step (explicit Euler kinematic bicycle)
@@ -155,6 +157,10 @@ int orc_mpc_step(const orc_params *p, double sx, double sy, double syaw, double 
                  int64_t target_ind, double speed, const double *oa_in, const double *od_in,
                  orc_step_out *out);
 
+int orc_mpc_step_cv(const orc_params *p, double sx, double sy, double syaw, double sv, const double *cx,
+                    const double *cy, const double *cyaw, const double *cv, int64_t cv_cut, int64_t ncourse,
+                    int64_t target_ind, double speed, const double *oa_in, const double *od_in, orc_step_out *out);
+
 /* Batched form used by bench.py's cpu_baseline and the parity tests.  Layouts are the product's
  * (include/jsim_mpc.h): x0 [B][4] = (x,y,v,yaw); oa/od [B][T] in/out; ox.. [B][T+1]; xref [B][4][T+1];
  * active_mask [B][ceil(8T/32)]; paths concatenated with path_off[n_paths+1]. Any output may be NULL.
@@ -165,6 +171,13 @@ int orc_mpc_step_batch(const orc_params *p, int32_t B, const double *x0, const i
                        int64_t *target_ind, double *oa, double *od, double *ox, double *oy,
                        double *ov, double *oyaw, double *xref, uint32_t *active_mask,
                        int32_t *status, int32_t *n_iter, int32_t n_threads);
+
+int orc_mpc_step_batch_cv(const orc_params *p, int32_t B, const double *x0, const int32_t *path_id,
+                          const int32_t *path_len, const double *speed, const double *cx,
+                          const double *cy, const double *cyaw, const double *cv, const int32_t *cv_cut,
+                          const int64_t *path_off, int64_t *target_ind, double *oa, double *od, double *ox,
+                          double *oy, double *ov, double *oyaw, double *xref, uint32_t *active_mask,
+                          int32_t *status, int32_t *n_iter, int32_t n_threads);
 
 double orc_xref_deviation(const double *cx, const double *cy, const double *cyaw, int64_t target_ind,
                           double ox0, double oy0);

@@ -128,6 +128,11 @@ def lib() -> C.CDLL:
         L.orc_mpc_step.restype = C.c_int
         L.orc_mpc_step_batch.argtypes = [C.POINTER(OrcParams), C.c_int32] + [C.c_void_p] * 19 + [C.c_int32]
         L.orc_mpc_step_batch.restype = C.c_int
+        L.orc_mpc_step_batch_cv.argtypes = [C.POINTER(OrcParams), C.c_int32] + [C.c_void_p] * 21 + [C.c_int32]
+        L.orc_mpc_step_batch_cv.restype = C.c_int
+        L.orc_mpc_step_cv.argtypes = [C.POINTER(OrcParams)] + [C.c_double] * 4 + [dp, dp, dp, C.c_void_p, C.c_int64,
+                                      C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(OrcStepOut)]
+        L.orc_mpc_step_cv.restype = C.c_int
         L.orc_xref_deviation.argtypes = [dp, dp, dp, C.c_int64, C.c_double, C.c_double]
         L.orc_xref_deviation.restype = C.c_double
         L.orc_is_goal.argtypes = [C.POINTER(OrcParams)] + [C.c_double] * 5 + [C.c_int64, C.c_int64]
@@ -207,8 +212,9 @@ def active_indices_from_mask(mask_row, m):
     return [i for i in range(m) if (int(mask_row[i >> 5]) >> (i & 31)) & 1]
 
 
-def mpc_step(p, state_xyyawv, cx, cy, cyaw, target_ind, speed, oa=None, od=None, want_qp=False):
-    """One reference MPC.step for one ego.  state = (x, y, yaw, v) like lib.simulation.State."""
+def mpc_step(p, state_xyyawv, cx, cy, cyaw, target_ind, speed, oa=None, od=None, want_qp=False, cv=None, cv_cut=-1):
+    """One reference MPC.step for one ego.  state = (x, y, yaw, v) like lib.simulation.State.
+    cv / cv_cut: the mpc_with_speed variant's per-point speed reference, zeroed from index cv_cut on."""
     T = p.T; n = 2 * T; m = 8 * T
     res = {
         "oa": np.zeros(T), "od": np.zeros(T), "ox": np.zeros(T + 1), "oy": np.zeros(T + 1),
@@ -226,9 +232,11 @@ def mpc_step(p, state_xyyawv, cx, cy, cyaw, target_ind, speed, oa=None, od=None,
     oa_c = _c(oa) if oa is not None else None
     od_c = _c(od) if od is not None else None
     sx, sy, syaw, sv = [float(v) for v in state_xyyawv]
-    st = lib().orc_mpc_step(C.byref(p), sx, sy, syaw, sv, cx, cy, cyaw, cx.shape[0], int(target_ind),
-                            float(speed), oa_c.ctypes.data if oa_c is not None else None,
-                            od_c.ctypes.data if od_c is not None else None, C.byref(out))
+    cv_c = _c(cv) if cv is not None else None
+    st = lib().orc_mpc_step_cv(C.byref(p), sx, sy, syaw, sv, cx, cy, cyaw, cv_c.ctypes.data if cv_c is not None else None,
+                               int(cv_cut), cx.shape[0], int(target_ind),
+                               float(speed), oa_c.ctypes.data if oa_c is not None else None,
+                               od_c.ctypes.data if od_c is not None else None, C.byref(out))
     res["status"] = int(st)
     res["n_iter"] = int(out.n_iter)
     res["target_ind"] = int(out.target_ind)
@@ -238,7 +246,7 @@ def mpc_step(p, state_xyyawv, cx, cy, cyaw, target_ind, speed, oa=None, od=None,
 
 
 def mpc_step_batch(p, x0, path_id, path_len, speed, cx, cy, cyaw, path_off, target_ind, oa, od,
-                   n_threads=1):
+                   n_threads=1, cv=None, cv_cut=None):
     """Batched oracle step with the product's [B][..] layouts.  Returns a dict of fresh arrays;
     oa/od/target_ind inputs are not modified."""
     B = x0.shape[0]; T = p.T; MW = (8 * T + 31) // 32
@@ -251,9 +259,11 @@ def mpc_step_batch(p, x0, path_id, path_len, speed, cx, cy, cyaw, path_off, targ
         "active_mask": np.zeros((B, MW), dtype=np.uint32), "status": np.zeros(B, dtype=np.int32),
         "n_iter": np.zeros(B, dtype=np.int32),
     }
-    ptr = lambda a: a.ctypes.data
-    lib().orc_mpc_step_batch(C.byref(p), B, ptr(x0), ptr(path_id), ptr(path_len), ptr(speed), ptr(cx),
-                             ptr(cy), ptr(cyaw), ptr(path_off), ptr(out["target_ind"]), ptr(out["oa"]),
+    ptr = lambda a: None if a is None else a.ctypes.data
+    cv = _c(cv) if cv is not None else None
+    cv_cut = _c(cv_cut, np.int32) if cv_cut is not None else None
+    lib().orc_mpc_step_batch_cv(C.byref(p), B, ptr(x0), ptr(path_id), ptr(path_len), ptr(speed), ptr(cx),
+                             ptr(cy), ptr(cyaw), ptr(cv), ptr(cv_cut), ptr(path_off), ptr(out["target_ind"]), ptr(out["oa"]),
                              ptr(out["od"]), ptr(out["ox"]), ptr(out["oy"]), ptr(out["ov"]),
                              ptr(out["oyaw"]), ptr(out["xref"]), ptr(out["active_mask"]),
                              ptr(out["status"]), ptr(out["n_iter"]), int(n_threads))

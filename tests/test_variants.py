@@ -1,0 +1,105 @@
+"""SURVEY.md 8 row f3 -- the data-only MPC variants.  CPU: module constants of the drop-in equal the reference's,
+the oracle's reference window with a speed reference equals `lib.mpc_with_speed._calc_ref_trajectory` (golden).
+GPU: variant configuration (weights, MAX_DECEL, cv + cut-off) against the oracle through the C-ABI; per-solve
+re-configuration (mpc_sensitivity)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _variant_params(oracle, T=13):
+    return oracle.make_params(T=T, config={"w_perp": 10.0, "w_para": 1.0, "Q_v_yaw": [20.0, 0.5], "MAX_DECEL": -5,
+                                           "STOP_SPEED": 0.5 / 3.6})
+
+
+def test_variant_constants(pkg):
+    g = load_golden("variant_with_speed.npz")
+    m = pkg.mpc_with_speed
+    assert m.T == int(g["c_T"]) and m.MAX_DECEL == float(g["c_MAX_DECEL"]) and m.MAX_SPEED == float(g["c_MAX_SPEED"])
+    assert np.array_equal(np.diag(m.Q_v_yaw), g["c_Q_v_yaw"]) and np.array_equal(np.diag(m.Qf), g["c_Qf_scaled"])
+    assert np.array_equal(np.diag(m.R), g["c_R"]) and np.array_equal(np.diag(m.Rd), g["c_Rd"])
+    assert m.STOP_SPEED == float(g["c_STOP_SPEED"]) and m.MAX_DSTEER == float(g["c_MAX_DSTEER"])
+    assert m.config.w_perp == 10.0 and m.config.Q_v_yaw == [20.0, 0.5] and m.config.MAX_DECEL == -5.0
+
+
+def test_oracle_reference_window_with_speed_reference(oracle, routes):
+    g = load_golden("variant_with_speed.npz")
+    p = _variant_params(oracle)
+    n_zero = 0
+    for b in range(len(g["x0"])):
+        r = routes[int(g["path_id"][b])][: int(g["path_len"][b])]
+        cv = np.full(len(r), float(g["c_MAX_SPEED"]))
+        cut = int(g["cutoff"][b])
+        x, y, v, yaw = g["x0"][b]
+        res = oracle.mpc_step(p, (x, y, yaw, v), r[:, 0], r[:, 1], r[:, 2], int(g["target_ind_in"][b]), 30 / 3.6,
+                              cv=cv, cv_cut=cut if cut != 999 else -1)
+        assert res["status"] in (0, 1)
+        assert res["target_ind"] == int(g["target_ind_out"][b])
+        assert np.array_equal(res["xref"], g["xref"][b])           # incl. row 2 = cv[idx] with the cut-off
+        n_zero += bool((g["xref"][b][2] == 0).any())
+    assert n_zero >= 5
+
+
+@pytest.mark.gpu
+def test_variant_gpu_vs_oracle(pkg, oracle, routes):
+    T, B = 13, 96
+    m = pkg.mpc_with_speed
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=9, truncate=True, near_end_frac=0.3)
+    rng = np.random.default_rng(3)
+    cut = np.where(rng.random(B) < 0.6, rng.integers(0, 720, size=B), -1).astype(np.int32)
+    cvs = [np.full(len(r), m.MAX_SPEED) for r in routes]
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False, config=m.config, cv=cvs)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    eng.set_speed_cutoff(cut)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+    torch.cuda.synchronize()
+    p = _variant_params(oracle, T)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    ref = oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off, batch.target_ind,
+                                batch.oa, batch.od, cv=np.concatenate(cvs), cv_cut=cut)
+    assert np.array_equal(eng.status.cpu().numpy(), ref["status"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy(), ref["xref"])
+    assert float(np.abs(ref["xref"][:, 2]).max()) > 0 and (ref["xref"][:, 2] == 0).any()
+    ok = ref["status"] == 0
+    assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-8
+    assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-8
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
+    # with a speed weight of 20 the reference speed matters: the plain controller on the same inputs differs
+    plain = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False)
+    plain.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    plain.solve(torch.from_numpy(batch.x0).to(eng.device))
+    assert float((plain.oa - eng.oa).abs().max()) > 1e-2
+
+
+@pytest.mark.gpu
+def test_variant_dropin_and_reconfiguration(pkg, oracle, routes):
+    m = pkg.mpc_with_speed
+    r = routes[0].copy()
+    cv = np.full(len(r), m.MAX_SPEED)
+    mpc = m.MPC(cx=r[:, 0], cy=r[:, 1], cv=cv, cyaw=r[:, 2].copy(), dl=pkg.synth.DL, car_dimensions=pkg.BicycleModelDimensions())
+    mpc.set_trajectory_fromarray(r, cutoff_idx=150)
+    st = pkg.State(x=r[60, 0], y=r[60, 1], yaw=r[60, 2], v=5.0)
+    mpc.target_ind = 55
+    di, ai = mpc.step(st)
+    p = _variant_params(oracle)
+    cvz = cv.copy(); cvz[150:] = 0
+    ref = oracle.mpc_step(p, (st.x, st.y, st.yaw, st.v), r[:, 0], r[:, 1], r[:, 2], 55, 30 / 3.6, cv=cvz)
+    assert mpc.status == ref["status"] == 0
+    assert abs(di - ref["od"][0]) <= 1e-8 and abs(ai - ref["oa"][0]) <= 1e-8
+    assert np.array_equal(mpc.xref, ref["xref"])
+    u1 = np.concatenate([mpc.oa, mpc.odelta])
+    # mpc_sensitivity: weights re-read before every solve -> update_config between solves
+    eng = mpc._engine
+    from dataclasses import replace
+    cfg2 = replace(m.config, w_perp=40.0, Q_v_yaw=[5.0, 0.5])
+    eng.update_config(cfg2)
+    mpc.oa = mpc.odelta = None
+    mpc.target_ind = 55
+    di2, ai2 = mpc.step(st)
+    p2 = oracle.make_params(T=13, config={"w_perp": 40.0, "Q_v_yaw": [5.0, 0.5], "MAX_DECEL": -5})
+    ref2 = oracle.mpc_step(p2, (st.x, st.y, st.yaw, st.v), r[:, 0], r[:, 1], r[:, 2], 55, 30 / 3.6, cv=cvz)
+    assert abs(di2 - ref2["od"][0]) <= 1e-8 and abs(ai2 - ref2["oa"][0]) <= 1e-8
+    np.testing.assert_allclose(np.concatenate([mpc.oa, mpc.odelta]), np.concatenate([ref2["oa"], ref2["od"]]), rtol=0, atol=1e-8)
+    assert np.abs(np.concatenate([mpc.oa, mpc.odelta]) - u1).max() > 1e-4   # the new weights changed the solution
