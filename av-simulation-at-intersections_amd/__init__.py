@@ -11,7 +11,7 @@ from .config import MPCConfig  # noqa: F401
 from .vehicle import State, BicycleModelDimensions  # noqa: F401
 from . import _cabi  # noqa: F401
 from .batched import BatchedMPC  # noqa: F401
-from .closed_loop import ClosedLoop, PreTick, car_circles  # noqa: F401
+from .closed_loop import ClosedLoop, PreTick, ScriptedObstacles, ScenarioLoop, car_circles  # noqa: F401
 from . import mpc  # noqa: F401
 from .mpc import MPC, MAX_ACCEL, MAX_DECEL, MPCSolutionNotFoundException  # noqa: F401
 from . import mpc_with_speed  # noqa: F401

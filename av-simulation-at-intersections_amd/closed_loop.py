@@ -140,3 +140,53 @@ class PreTick:
             _ptr(self.col_flag), _ptr(self.col_xy), _ptr(self.first_idx), _ptr(self.status), self.frame_window,
             self.margin, _ptr(dbg_idx), _ptr(dbg_n), eng._stream()), eng._ctx, "jsim_loop_pre_tick")
         self.prev_len.copy_(eng.path_len)
+
+
+class ScriptedObstacles:
+    """Device-resident `MovingObstacleTIntersection` vehicles (main/lib/moving_obstacles.py:166-232).
+    specs: list of dicts(direction=+-1, turning=bool, speed=float, offset=float|None) like the scenario builds them
+    (main/scenarios/mpc_intersection.py:46-49)."""
+
+    def __init__(self, engine: BatchedMPC, specs, dt: Optional[float] = None):
+        self.eng = engine
+        dt = engine.dt if dt is None else dt
+        st, pr = [], []
+        for s in specs:
+            d = 1.0 if s.get("direction", 1) >= 0 else -1.0
+            off = s.get("offset", None)
+            off = float(off) if (off is not None and off > 0) else 0.0
+            if d > 0:
+                st.append([-30.0, -3.0, 0.0, 0.0]); x_turn = -10.0
+            else:
+                st.append([30.0, 3.0, math.pi, 0.0]); x_turn = 12.0
+            pr.append([d, 1.0 if s.get("turning", False) else 0.0, float(s["speed"]), off, x_turn, float(dt)])
+        dev = engine.device
+        self.n = len(specs)
+        self.state = torch.tensor(st, dtype=torch.float64, device=dev).reshape(self.n, 4)
+        self.param = torch.tensor(pr, dtype=torch.float64, device=dev).reshape(self.n, 6)
+        self.get_buf = torch.zeros(max(self.n, 1), 6, dtype=torch.float64, device=dev)
+
+    def get(self, step: bool = False) -> torch.Tensor:
+        """The `o.get()` tuples of all obstacles ([n, 6] device tensor); step=True also applies `o.step()` afterwards."""
+        eng = self.eng
+        _cabi.check(eng.lib.jsim_loop_obstacles(eng._ctx, self.n, _ptr(self.state), _ptr(self.param), _ptr(self.get_buf),
+                                                1 if step else 0, eng._stream()), eng._ctx, "jsim_loop_obstacles")
+        return self.get_buf[: self.n]
+
+
+class ScenarioLoop:
+    """The reference scenario loop for a batch, entirely on the device (main/scenarios/mpc_intersection.py:99-163):
+    obstacle get() -> prediction -> progress index / resample / collision / cut-off -> MPC.step -> plant, history, goal ->
+    obstacle step()."""
+
+    def __init__(self, engine: BatchedMPC, x0: torch.Tensor, obstacle_specs, hist_cap: int = 0, max_age: int = 0):
+        self.loop = ClosedLoop(engine, x0, hist_cap=hist_cap, max_age=max_age)
+        self.pre = PreTick(engine)
+        self.obst = ScriptedObstacles(engine, obstacle_specs)
+
+    def tick(self):
+        g = self.obst.get(step=False)
+        self.pre.predict(g)
+        self.pre.run(self.loop.x0)
+        self.loop.tick()
+        self.obst.get(step=True)

@@ -1483,3 +1483,16 @@ extern "C" int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg)
     ctx->cfg = *cfg;
     return 0;
 }
+
+extern "C" int jsim_loop_obstacles(jsim_ctx *ctx, int32_t n_obs, double *state, const double *param, double *get, int32_t do_step,
+                                   void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_obstacles: null ctx");
+    if (n_obs < 0 || n_obs > JSIM_MAX_OBS) return fail(ctx, -22, "jsim_loop_obstacles: n_obs=%d (max %d)", n_obs, JSIM_MAX_OBS);
+    if (n_obs == 0) return 0;
+    if (!state || !param) return fail(ctx, -22, "jsim_loop_obstacles: null device pointer");
+    ObsStepP P = {n_obs, do_step ? 1 : 0, ctx->cfg.L, state, param, get};
+    hipLaunchKernelGGL(obstacle_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

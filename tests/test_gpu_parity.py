@@ -448,3 +448,48 @@ def test_degenerate_paths_and_positions(pkg, oracle):
     ok = ref["status"] == 0
     assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-8
     assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
+
+
+def test_scripted_obstacles_vs_reference(pkg, routes):
+    g = load_golden("obstacles_scripted.npz")
+    eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
+    specs = [dict(direction=int(d), turning=bool(t), speed=float(s), offset=None if o < 0 else float(o))
+             for d, t, s, o in zip(g["direction"], g["turning"], g["speed"], g["offset"])]
+    ob = pkg.ScriptedObstacles(eng, specs)
+    turned = False
+    for k in range(g["get"].shape[0]):
+        got = ob.get(step=True).cpu().numpy()
+        np.testing.assert_allclose(got, g["get"][k], rtol=0, atol=1e-11)
+        turned |= bool((got[:, 5] != 0).any())
+    assert turned     # the scripted turns (steer -0.38 / 0.19) happened
+
+
+def test_scenario_loop_on_device_config1(pkg, routes):
+    """The whole mpc_intersection loop (config 1: 1 ego, T = 13, the scenario's two scripted obstacles) run on the device
+    tick by tick -- obstacles, prediction, collision cut-off, MPC, plant -- against the recorded reference loop."""
+    g = load_golden("loop_closed_T13.npz")
+    full = routes[int(g["route_id"])]
+    dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+    eng = pkg.BatchedMPC([full.copy()], [0], dl=dl, T=13, smooth=False)
+    x0 = torch.tensor([[full[0, 0], full[0, 1], 0.0, full[0, 2]]], dtype=torch.float64, device=eng.device)
+    K = len(g["ticks"])
+    sc = pkg.ScenarioLoop(eng, x0, [dict(direction=1, offset=2., turning=False, speed=25 / 3.6),
+                                    dict(direction=-1, offset=4., turning=True, speed=25 / 3.6)], hist_cap=K, max_age=0)
+    n_cut = 0
+    for k, row in enumerate(g["ticks"]):
+        x, y, yaw, v = row[:4]
+        st = sc.loop.x0[0].cpu().numpy()
+        np.testing.assert_allclose(st, [x, y, v, yaw], rtol=0, atol=1e-6)
+        sc.tick()
+        assert int(sc.pre.traj_idx.item()) == int(row[6]) and int(eng.path_len.item()) == int(row[7])
+        assert int(eng.status.item()) == int(row[11])
+        if k < K - 1:     # the last recorded tick ends at the goal: the device loop respawns the ego (target_ind -> 0)
+            assert int(eng.target_ind.item()) == int(row[10]) and int(sc.loop.n_respawn.item()) == 0
+        n_cut += int(sc.pre.col_flag.item())
+    hist = sc.loop.hist[:K, 0].cpu().numpy()
+    np.testing.assert_allclose(hist[:, 0], g["ticks"][:, 12], rtol=0, atol=1e-6)   # delta
+    np.testing.assert_allclose(hist[:, 1], g["ticks"][:, 13], rtol=0, atol=1e-6)   # acceleration
+    assert n_cut == int(g["ticks"][:, 8].sum())
+    # after the last recorded tick the reference loop's next iteration finds mpc.is_goal(state) and breaks; here: respawn
+    assert bool(g["reached_goal"]) and int(sc.loop.n_respawn.item()) == 1
+    np.testing.assert_array_equal(sc.loop.x0.cpu().numpy(), x0.cpu().numpy())
