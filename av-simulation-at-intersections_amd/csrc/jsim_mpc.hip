@@ -35,6 +35,26 @@
 #include "jsim_mpc.h"
 
 #define JSIM_VIOL_TOL 1e-10
+// Entering-row key: viol^2 / (n'H^-1 n) with its low 9 mantissa bits cleared (keys closer than 2^-43 relative count as
+// tied and go to the lowest canonical row id, < 512).  The register kernel stores 511 - id in those 9 bits.
+__device__ __forceinline__ double jsim_key_trunc(double k)
+{
+    return __hiloint2double(__double2hiint(k), __double2loint(k) & ~511);
+}
+// Dual ratio test: a step length keeps its upper 57 bits (the low 7 are cleared; the register kernel stores the
+// working-set position there), steps closer than 2^-45 relative are ties -> lowest position.
+__device__ __forceinline__ double jsim_ratio_trunc(double t)
+{
+    return __hiloint2double(__double2hiint(t), __double2loint(t) & ~127);
+}
+__device__ __forceinline__ double jsim_ratio_pack(double t, int k)
+{
+    return __hiloint2double(__double2hiint(t), (__double2loint(t) & ~127) | k);
+}
+__device__ __forceinline__ double jsim_key_pack(double k, int id)
+{
+    return __hiloint2double(__double2hiint(k), (__double2loint(k) & ~511) | (511 - id));
+}
 #define JSIM_DEP_TOL 1e-18
 #define JSIM_ACT_TOL 1e-9
 #define JSIM_FEAS_TOL 1e-8
@@ -64,7 +84,7 @@ struct KP {
     long long *dbg_idx;
     double *dbg_H, *dbg_g, *dbg_lam;
     long long *dbg_clk; // diagnostic build only (-DJSIM_STAMPS): [B][16] s_memtime stamps at phase boundaries
-    int dbg_max_gi;     // timing experiments only (env JSIM_DEBUG_MAX_GI): stop the active-set loop after this many
+    int dbg_max_gi;     // diagnostic builds only (-DJSIM_STAMPS / -DJSIM_SPAN, env JSIM_DEBUG_MAX_GI): stop the active-set loop after this many
                         // outer iterations (results are then NOT the optimum); -1 = off
 };
 
@@ -75,6 +95,8 @@ struct KP {
 
 #ifdef JSIM_STAMPS
 #define STAMP(i) do { if (P.dbg_clk && lane == 0) P.dbg_clk[(size_t)ego * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#elif defined(JSIM_SPAN) /* only the first and the last stamp of a step: two s_memtime per solve, nothing else changes */
+#define STAMP(i) do { if (((i) == 0 || (i) == 11) && P.dbg_clk && lane == 0) P.dbg_clk[(size_t)ego * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
     if ((valid) && !(abits & (1u << (bit)))) {                                           \
         const double vv = (viol_expr);                                                   \
         const int id_ = (id_expr);                                                       \
-        const double key_ = vv * vv * (iw);                                              \
+        const double key_ = jsim_key_trunc(vv * vv * (iw));                              \
         if (vv > JSIM_VIOL_TOL * (1.0 + (habs)) && (key_ > best || (key_ == best && id_ < bid))) { best = key_; bid = id_; bviol = vv; } \
     }
             CONSIDER(t + 1 < T, 0, (dnext - dl_) - P.dmax, P.dmax, 2 * t, iwD)
@@ -731,7 +753,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
                 for (int rr = 0; rr < RPL; ++rr) {
                     const int k = lane + 64 * rr;
                     if (k < q && r[rr] > 0.0) {
-                        double tk = lamv[k] / r[rr];
+                        double tk = jsim_ratio_trunc(lamv[k] / r[rr]);
                         if (tk < bt) { bt = tk; bk = k; }
                     }
                 }
@@ -1340,7 +1362,7 @@ extern "C" int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *o
     return 0;
 }
 
-#ifdef JSIM_STAMPS
+#if defined(JSIM_STAMPS) || defined(JSIM_SPAN)
 // diagnostic build only (not declared in include/jsim_mpc.h, not built into libjsim_mpc.so)
 extern "C" int jsim_debug_set_clock_buffer(jsim_ctx *ctx, long long *dev_buf)
 {

@@ -8,6 +8,7 @@
 #include "mpc_oracle.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -370,6 +371,27 @@ int orc_build_qp(const orc_params *p, const double *xref, const double *xbar, co
 #define ORC_VIOL_TOL 1e-10
 #define ORC_DEP_TOL 1e-18 /* ||d2||^2 <= tol * ||d||^2  => normal is in the span of the working set */
 
+/* Entering-row key with its low 9 mantissa bits cleared: keys closer than 2^-43 relative are ties -> lowest row id.
+ * (Same rule as csrc/jsim_mpc.hip: jsim_key_trunc.) */
+static double orc_key_trunc(double k)
+{
+    uint64_t b;
+    memcpy(&b, &k, 8);
+    b &= ~(uint64_t)511;
+    memcpy(&k, &b, 8);
+    return k;
+}
+
+/* Dual step length with its low 7 mantissa bits cleared (ties -> lowest working-set position); jsim_ratio_trunc. */
+static double orc_ratio_trunc(double t)
+{
+    uint64_t b;
+    memcpy(&b, &t, 8);
+    b &= ~(uint64_t)127;
+    memcpy(&t, &b, 8);
+    return t;
+}
+
 int orc_solve_qp(int n, int m, const double *H, const double *g, const double *G, const double *h,
                  const uint8_t *skip, double *u, double *lam, int32_t *n_iter_out)
 {
@@ -449,7 +471,7 @@ int orc_solve_qp(int n, int m, const double *H, const double *g, const double *G
             double s = -h[i];
             for (int c = 0; c < n; ++c) s += G[i * n + c] * u[c];
             if (s > ORC_VIOL_TOL * (1.0 + fabs(h[i]))) {
-                const double key = s * s / wgt[i];
+                const double key = orc_key_trunc(s * s / wgt[i]);
                 if (key > vmax) {
                     vmax = key;
                     p = i;
@@ -487,7 +509,7 @@ int orc_solve_qp(int n, int m, const double *H, const double *g, const double *G
             double t1 = INFINITY;
             for (int k = 0; k < q; ++k) {
                 if (r[k] > 0.0) {
-                    double tk = lact[k] / r[k];
+                    double tk = orc_ratio_trunc(lact[k] / r[k]);
                     if (tk < t1) { t1 = tk; l = k; }
                 }
             }

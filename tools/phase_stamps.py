@@ -59,3 +59,10 @@ tot_it = itacc.sum()
 print(f"active-set loop: {tot_it:.0f} iterations over {len(itacc)} solves (mean {itacc.mean():.1f}); cycles per iteration by section:")
 for k, nme in enumerate(gn):
     print(f"  {nme:20s} {gacc[:, k].sum() / max(tot_it, 1):8.0f} cyc/iter   {100 * gacc[:, k].sum() / gacc.sum():5.1f} %")
+
+# per-solve regression: cycles of the active-set phase and of the whole step against the iteration count
+A = np.vstack([np.ones_like(itacc), itacc]).T
+for nme, y in (("active-set loop", acc[:, 9]), ("whole step", tot), ("u0 phase", acc[:, 8])):
+    coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+    print(f"  fit {nme:16s} = {coef[0]:9.0f} + {coef[1]:7.0f} * n_iter cycles")
+per_ego = tot.reshape(-1, ok.sum()) if False else None
