@@ -25,7 +25,7 @@ def _hipcc() -> str:
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
-    deps = [SRC, os.path.join(_HERE, "csrc", "mpc_step_reg.inc"), os.path.join(_HERE, "csrc", "loop_pre_tick.inc"), os.path.join(INC, "jsim_mpc.h")]
+    deps = [SRC, os.path.join(_HERE, "csrc", "mpc_step_reg.inc"), os.path.join(_HERE, "csrc", "mpc_step_reg2.inc"), os.path.join(_HERE, "csrc", "loop_pre_tick.inc"), os.path.join(INC, "jsim_mpc.h")]
     return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
 
 

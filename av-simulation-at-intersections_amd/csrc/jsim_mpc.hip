@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "jsim_mpc.h"
@@ -944,6 +945,26 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
 }
 
 #include "mpc_step_reg.inc"
+#include "mpc_step_reg2.inc"
+
+// horizons with a register-resident kernel: 3T+1 <= 64 lanes -> one wavefront per ego; T = 30 / 40 -> two wavefronts per ego
+#ifndef JSIM_REG2_T_A
+#define JSIM_REG2_T_A 30
+#endif
+#ifndef JSIM_REG2_T_B
+#define JSIM_REG2_T_B 40
+#endif
+static bool has_reg_kernel(int T) { return T == 13 || T == 20 || T == JSIM_REG2_T_A || T == JSIM_REG2_T_B; }
+static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K)
+{
+    if (T == 13) hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
+    else if (T == 20) hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
+    else if (T == JSIM_REG2_T_A) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_A>, dim3(B), dim3(128), 0, s, P, K);
+#if JSIM_REG2_T_B != JSIM_REG2_T_A
+    else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_B>, dim3(B), dim3(128), 0, s, P, K);
+#endif
+}
+
 #include "loop_pre_tick.inc"
 
 // ---------------------------------------------------------------------------------------------------
@@ -1154,7 +1175,7 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     // JSIM_FORCE_LDS_KERNEL=1 routes those through the generic LDS-resident kernel too (used by the tests to
     // cover both kernels on the same inputs)
     const char *force = getenv("JSIM_FORCE_LDS_KERNEL");
-    c->use_reg_kernel = (cfg->T == 13 || cfg->T == 20) && !(force && force[0] == '1');
+    c->use_reg_kernel = has_reg_kernel(cfg->T) && !(force && force[0] == '1');
     const char *mg = getenv("JSIM_DEBUG_MAX_GI");
     c->dbg_max_gi = mg ? atoi(mg) : -1;
     *out = c;
@@ -1275,10 +1296,7 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
     TickP K;
     memset(&K, 0, sizeof(K));
     K.n_ticks = 1; // plain MPC.step: one tick, no plant/bookkeeping
-    if (ctx->use_reg_kernel && c.T == 13)
-        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
-    else if (ctx->use_reg_kernel && c.T == 20)
-        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
+    if (ctx->use_reg_kernel) launch_reg(c.T, B, s, P, K);
     else if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
     else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
     HIP_TRY(ctx, hipGetLastError());
@@ -1389,7 +1407,7 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_run_ticks: jsim_mpc_set_paths has not been called");
     const jsim_cfg &c = ctx->cfg;
     hipStream_t s = (hipStream_t)stream;
-    if (!(ctx->use_reg_kernel && (c.T == 13 || c.T == 20))) {
+    if (!ctx->use_reg_kernel) {
         // horizons without the fused register kernel: the same ticks as separate launches
         for (int k = 0; k < n_ticks; ++k) {
             int rc = launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref,
@@ -1413,10 +1431,7 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     K.max_decel = c.max_decel; K.goal_dis = c.goal_dis; K.stop_speed = c.stop_speed;
     K.x0w = x0; K.di_ai = di_ai; K.x0_spawn = x0_spawn; K.target_spawn = (const long long *)target_spawn; K.age = age;
     K.hist = hist; K.tick = tick; K.n_respawn = (unsigned long long *)n_respawn;
-    if (c.T == 13)
-        hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
-    else
-        hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
+    launch_reg(c.T, B, s, P, K);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
