@@ -184,17 +184,19 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{B}-ego batch per GPU, kinematic bicycle, horizon N={T}, nu=2, fp64, closed loop "
-                                   f"(BASELINE.json configs[1])", "egos_per_gpu": B, "horizon": T,
+                                   f"({'BASELINE.json configs[1]' if (B, T) == (256, 20) else 'not the headline config'})", "egos_per_gpu": B, "horizon": T,
                        "launch": {"fused": f"fused closed loop, {chunk} ticks per launch", "graph": "hipGraph",
                                   "eager": "eager"}[mode], "parallelism": f"ego-shard x{world}",
                        "mean_active_set_iters": round(mean_iter, 2), "failed_egos_last_tick": n_fail,
                        "respawns": int(loop.n_respawn.item())},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": f"mpc_step_reg_kernel<{T}>" if T in (13, 20) else "mpc_step_kernel", "kernel_ms": kern_ms,
+                         "kernel": (f"mpc_step_reg_kernel<{T}>" if T in (13, 20) else
+                                    f"mpc_step_reg2_kernel<{T}>" if T in (30, 40) else "mpc_step_kernel"), "kernel_ms": kern_ms,
                          "ticks_per_launch": ticks_per_launch,
                          "algorithmic_flops_per_launch": flops,
-                         "note": "fp64 vector/matrix peak; latency-bound: one wave per CU at B=256 on 256 CUs"},
+                         "note": ("fp64 vector/matrix peak; latency-bound: " +
+                                  (f"{1 if T <= 21 else 2} wave(s) per ego, {B} egos on 256 CUs (1024 SIMDs)"))},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes},
         }

@@ -493,3 +493,31 @@ def test_scenario_loop_on_device_config1(pkg, routes):
     # after the last recorded tick the reference loop's next iteration finds mpc.is_goal(state) and breaks; here: respawn
     assert bool(g["reached_goal"]) and int(sc.loop.n_respawn.item()) == 1
     np.testing.assert_array_equal(sc.loop.x0.cpu().numpy(), x0.cpu().numpy())
+
+
+@pytest.mark.parametrize("T", (30, 40))
+def test_two_wave_kernel_large_working_sets(pkg, oracle, routes, T):
+    """Tight limits (0.05 m/s^2, 0.4 deg/s steer rate) make most of the 8T rows bind: the working set outgrows one
+    wavefront's 64 lanes at T = 40, which is the only way to reach the second position slot of mpc_step_reg2_kernel
+    (and long Givens sweeps of drops) from a test.  Compared with the oracle under the same configuration."""
+    B = 64
+    cfg = pkg.MPCConfig.from_json()
+    cfg.MAX_ACCEL, cfg.MAX_DECEL, cfg.MAX_DSTEER = 0.05, -0.05, 0.4
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=5, truncate=False, near_end_frac=0.0)
+    batch.oa[:] = 0.0
+    batch.od[:] = 0.0
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False, config=cfg)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+    torch.cuda.synchronize()
+    p, ref = _oracle_batch(oracle, pkg, routes, batch, T, config={"MAX_ACCEL": 0.05, "MAX_DECEL": -0.05, "MAX_DSTEER": 0.4})
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st, ref["status"])
+    ok = st == 0
+    assert ok.sum() >= B // 2
+    nact = np.unpackbits(ref["active_mask"].view(np.uint8), axis=1).sum(axis=1)
+    print(f"T={T}: active rows per ego: mean {nact[ok].mean():.1f}, max {nact[ok].max()}; n_iter max {ref['n_iter'].max()}")
+    assert nact[ok].max() > (64 if T == 40 else 40)
+    assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-6
+    assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-6
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32)[ok], ref["active_mask"][ok])
