@@ -1,61 +1,93 @@
 #!/usr/bin/env python3
-"""Turn profiles/r01_bench_fused_pmc_summary.json (+ the bench line of the profiled run) into profiles/r01_SUMMARY.txt."""
+"""profiles/ from the rocprofv3 runs of tools/collect_profile.sh:
+    summarize_profile.py TAG_default [TAG_other ...]
+TAG_default = the run of the default bench (256 egos, T = 20): writes r01_bench_fused_pmc_summary.json (read by bench.py
+for `roofline.traffic`), r01_bench_fused_kernel_stats.csv, r01_bench_fused_under_rocprof.json and r01_SUMMARY.txt;
+every other TAG adds r01_<TAG>_pmc_summary.json and a paragraph."""
 import json
 import os
+import shutil
+import glob
+import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(REPO, "profiles")
-p = json.load(open(os.path.join(P, "r01_bench_fused_pmc_summary.json")))
-bench = json.loads(open(os.path.join(P, "r01_bench_fused_under_rocprof.json")).read())
-launch_ms = p["fused_launch_ms_kernel_trace"]
-egosteps = 50 * 256
-traffic = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
-clk_ghz = p["GRBM_GUI_ACTIVE"] / 8 / launch_ms / 1e6
-txt = f"""Round 1 -- rocprofv3 evidence for the default bench (python bench.py --steps 100 --warmup 10, fused mode)
-=====================================================================================================
-Commands (each its own run, from /tmp with TMPDIR=/tmp, program after `--`):
-  rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE ...            (TCC: 3 slots)
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE ...            (TCC: 2 slots)
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_ACTIVE_INST_VALU ...
-  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE ...
+tags = sys.argv[1:]
 
-Dominant kernel: mpc_step_reg_kernel<20>(KP, TickP); the timed region consists of 2 launches of 50 ticks x 256 egos
-(the other 111 dispatches of the same kernel in r01_bench_fused_kernel_stats.csv are single-tick launches: 10 warm-up
-ticks, 1 untimed first use, 100 event-bracketed single ticks after the timed region -- avg {p['single_tick_launch_ms_kernel_trace']:.3f} ms each).
 
-Fused launch (50 ticks, 256 waves, one per CU):
-  duration (kernel trace)            {launch_ms:.2f} ms   (bench.py HIP events in the same run: {bench['roofline']['kernel_ms']:.2f} ms)
-  => 12,800 MPC steps per launch; bench line of the profiled run: {bench['value'] / 1e6:.2f} M steps/s
-  FETCH_SIZE                         {p['FETCH_SIZE']:.0f} KiB   (gfx950 counts 64 B per 128-B request on wide coalesced reads -> x2)
-  WRITE_SIZE                         {p['WRITE_SIZE']:.0f} KiB
-  HBM traffic (2*FETCH + WRITE)      {traffic / 1e6:.2f} MB per launch = {traffic / egosteps:.0f} B per MPC step
-                                     (algorithmic figure of SURVEY 8d: 2564 B/step; state stays in registers across the
-                                      50 ticks and the 200-KB path table is cache-resident, so less than that reaches HBM)
-  achieved HBM rate                  {traffic / launch_ms / 1e6:.2f} GB/s  = {traffic / launch_ms / 1e6 / 8000 * 100:.4f} % of 8 TB/s   (not the binding resource)
-  SQ_INSTS_VALU                      {p['SQ_INSTS_VALU'] / egosteps:.0f} wave-instructions per MPC step
-  SQ_INSTS_VALU_FMA_F64              {p['SQ_INSTS_VALU_FMA_F64'] / egosteps:.0f} per MPC step  -> {p['SQ_INSTS_VALU_FMA_F64'] * 128 / launch_ms / 1e9:.2f} TFLOP/s fp64 FMA executed (incl. idle lanes)
-  SQ_INSTS_VALU_MFMA_F64             {p['SQ_INSTS_VALU_MFMA_F64'] / egosteps:.0f} per MPC step (v_mfma_f64_16x16x4_f64; = the 56 non-zero (tile, time-step) pairs at T=20)
-  SQ_VALU_MFMA_BUSY_CYCLES           {p['SQ_VALU_MFMA_BUSY_CYCLES']:.3g}  = {p['SQ_VALU_MFMA_BUSY_CYCLES'] / p['SQ_INSTS_VALU_MFMA_F64']:.0f} cycles per MFMA
-  GRBM_GUI_ACTIVE / 8 XCDs           {p['GRBM_GUI_ACTIVE'] / 8:.3g} cycles -> {clk_ghz:.2f} GHz effective clock
-  MFMA utilisation                   {p['SQ_VALU_MFMA_BUSY_CYCLES'] / (p['GRBM_GUI_ACTIVE'] / 8 * 1024) * 100:.2f} % of all 1024 SIMDs ({p['SQ_VALU_MFMA_BUSY_CYCLES'] / (p['GRBM_GUI_ACTIVE'] / 8 * 256) * 100:.2f} % of the 256 SIMDs that hold a wave)
-  SQ_WAIT_ANY / SQ_WAVE_CYCLES       {p['SQ_WAIT_ANY'] / p['SQ_WAVE_CYCLES'] * 100:.0f} % of wave lifetime parked on s_waitcnt (LDS / scalar loads), issue-stalled {p['SQ_WAIT_INST_ANY'] / p['SQ_WAVE_CYCLES'] * 100:.0f} %
-  SQ_INSTS_LDS                       {p['SQ_INSTS_LDS'] / egosteps:.0f} per MPC step, bank-conflict cycles {p['SQ_LDS_BANK_CONFLICT'] / egosteps:.0f} per step
-  SQ_WAVES                           256 (one wave per CU: the shape is latency-bound by construction)
+def load(tag):
+    return json.load(open(os.path.join(REPO, "gpurun_out", tag, "summary.json")))
 
-Reading: the path moves ~{traffic / egosteps:.0f} B/step and executes ~{p['SQ_INSTS_VALU'] / egosteps / 1000:.0f}k wave instructions/step on ONE wave per CU; it is bound by the
-dependent-issue latency of a single wavefront (SURVEY D6), not by HBM and not by MFMA throughput.
 
-History of the same measurement within round 1 (bench.py, 1 GPU, 256 egos, T = 20):
-  v1 LDS-resident kernel, one launch per tick              0.37 M steps/s   (0.67 ms per single-tick launch)   r01_v1_lds_*
-  register-resident kernel, one launch per tick            0.82 M           (0.38 ms)
-  + fused closed loop (50 ticks per launch)                1.54 M           (26k VALU wave-instr per step)
-  + steepest-edge entering rule (-35 % iterations)         2.00 M
-  + burst LDS reads behind sched barriers                  2.24 M           (18k VALU wave-instr per step)
-Files: r01_bench_fused_kernel_stats.csv (rocprofv3 --stats), r01_bench_fused_pmc_summary.json (per-launch counter means),
-r01_bench_fused_under_rocprof.json (the bench line printed in the profiled run), r01_bench_default.json (plain `python bench.py`),
-r01_reg_kernel_phase_stamps_T20.txt (diagnostic -DJSIM_STAMPS build: per-phase / per-section cycle shares; that build spills
-and its absolute times -- the `u0` phase in particular -- are not those of the shipped kernel), r01_v1_lds_* (first kernel).
+def para(p, title):
+    b = p["bench_line_under_rocprof"]
+    B, T, tpl = b["config"]["egos_per_gpu"], b["config"]["horizon"], b["roofline"]["ticks_per_launch"]
+    steps = B * tpl
+    ms = p["fused_launch_ms_kernel_trace"]
+    traffic = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+    clk = p["GRBM_GUI_ACTIVE"] / 8 / ms / 1e6
+    waves = p["SQ_WAVES"]
+    simds = min(waves, 1024)
+    return f"""{title}
+  kernel                             {p['kernel']}   ({p['fused_launches']} fused launches of {tpl} ticks x {B} egos in the timed region)
+  duration (kernel trace)            {ms:.3f} ms   (bench.py HIP events in the same run: {b['roofline']['kernel_ms']:.3f} ms)
+  => {steps} MPC steps per launch; bench line of the profiled run: {b['value'] / 1e6:.2f} M steps/s, mean {b['config']['mean_active_set_iters']} active-set iterations
+  FETCH_SIZE / WRITE_SIZE            {p['FETCH_SIZE']:.0f} / {p['WRITE_SIZE']:.0f} KiB   (gfx950 counts 64 B per 128-B request on wide coalesced reads -> FETCH x2)
+  HBM traffic (2*FETCH + WRITE)      {traffic / 1e6:.2f} MB per launch = {traffic / steps:.0f} B per MPC step   (algorithmic, SURVEY 8d: {8 * (15 * T + 16) + 16 + T} B/step)
+  achieved HBM rate                  {traffic / ms / 1e6:.2f} GB/s = {traffic / ms / 1e6 / 8000 * 100:.4f} % of 8 TB/s   (not the binding resource)
+  SQ_INSTS_VALU / _SALU / _LDS       {p['SQ_INSTS_VALU'] / steps:.0f} / {p['SQ_INSTS_SALU'] / steps:.0f} / {p['SQ_INSTS_LDS'] / steps:.0f} wave-instructions per MPC step
+  SQ_INSTS_VALU_FMA_F64              {p['SQ_INSTS_VALU_FMA_F64'] / steps:.0f} per MPC step -> {p['SQ_INSTS_VALU_FMA_F64'] * 128 / ms / 1e9:.2f} TFLOP/s fp64 FMA executed (incl. idle lanes)
+  SQ_INSTS_VALU_MFMA_F64             {p['SQ_INSTS_VALU_MFMA_F64'] / steps:.0f} per MPC step (v_mfma_f64_16x16x4_f64), {p['SQ_VALU_MFMA_BUSY_CYCLES'] / p['SQ_INSTS_VALU_MFMA_F64']:.0f} busy cycles each
+  MFMA utilisation                   {p['SQ_VALU_MFMA_BUSY_CYCLES'] / (p['GRBM_GUI_ACTIVE'] / 8 * 1024) * 100:.2f} % of all 1024 SIMDs
+  GRBM_GUI_ACTIVE / 8 XCDs           {p['GRBM_GUI_ACTIVE'] / 8:.3g} cycles -> {clk:.2f} GHz effective clock
+  wave lifetime                      VALU busy {p['SQ_ACTIVE_INST_VALU'] / p['SQ_WAVE_CYCLES'] * 100 * (4 if False else 1):.0f} % (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), waiting on s_waitcnt {p['SQ_WAIT_ANY'] / p['SQ_WAVE_CYCLES'] * 100:.0f} %, issue-stalled {p['SQ_WAIT_INST_ANY'] / p['SQ_WAVE_CYCLES'] * 100:.0f} %
+  SQ_WAVES                           {waves:.0f} ({waves / 256:.0f} per CU over the launch); LDS bank-conflict cycles {p['SQ_LDS_BANK_CONFLICT'] / steps:.0f} per step
+"""
+
+
+main = load(tags[0])
+keep = {k: v for k, v in main.items() if k not in ("bench_line_under_rocprof", "kernel_stats")}
+json.dump(keep, open(os.path.join(P, "r01_bench_fused_pmc_summary.json"), "w"), indent=1)
+json.dump(main["bench_line_under_rocprof"], open(os.path.join(P, "r01_bench_fused_under_rocprof.json"), "w"))
+st = glob.glob(os.path.join(REPO, "gpurun_out", tags[0], "trace", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(P, "r01_bench_fused_kernel_stats.csv"))
+txt = """Round 1 -- rocprofv3 evidence (tools/collect_profile.sh: one --kernel-trace --stats run and four separate --pmc passes
+per configuration, from /tmp with TMPDIR=/tmp, `python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline [...]` after `--`)
+=====================================================================================================================
+"""
+txt += para(main, "Default bench: 256 egos, T = 20, fused closed loop (BASELINE.json configs[1])")
+txt += """
+Reading: one wave per CU, ~15k VALU wave-instructions per step at ~5.3 cycles each (tools/ubench/issue_cost.hip: every VALU
+instruction of a lone wave issues in >= 5.3 cycles, a dependent FMA chain in 8.3, FMA->readlane->FMA in 26, a uniform
+branch in ~40, a ds_write_b128 in 25): the path is bound by the issue latency of a single wavefront (SURVEY D6), not by
+HBM and not by MFMA throughput.  The launch time is set by the slowest of the 256 egos (tools/wave_span.py: the mean
+step takes 65.7k + 6.06k * n_iter cycles, the slowest ego averages 21 iterations against a fleet mean of 10.9).
+"""
+for t in tags[1:]:
+    p = load(t)
+    json.dump({k: v for k, v in p.items() if k not in ("bench_line_under_rocprof", "kernel_stats")},
+              open(os.path.join(P, f"r01_{t}_pmc_summary.json"), "w"), indent=1)
+    st = glob.glob(os.path.join(REPO, "gpurun_out", t, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(P, f"r01_{t}_kernel_stats.csv"))
+    b = p["bench_line_under_rocprof"]
+    txt += "\n" + para(p, f"{b['config']['egos_per_gpu']} egos, T = {b['config']['horizon']} (two wavefronts per ego)")
+txt += """
+History of the default bench within round 1 (bench.py, 1 GPU, 256 egos, T = 20):
+  v1 LDS-resident kernel, one launch per tick                      0.37 M steps/s   (0.67 ms per single-tick launch)   r01_v1_lds_*
+  register-resident kernel, one launch per tick                    0.82 M
+  + fused closed loop (50 ticks per launch)                        1.54 M           (26k VALU wave-instr per step)
+  + steepest-edge entering rule (-35 % iterations)                 2.00 M
+  + burst LDS reads behind sched barriers                          2.24 M           (18k VALU wave-instr per step)
+  + packed 64-bit arg-max / arg-min, pair candidates, L prefetch   2.38 M
+  + arithmetic pinned where written (no AGPR round trips)          2.60 M           (15k VALU wave-instr per step)
+Horizons 30 / 40 (4096 egos): LDS-resident kernel 0.84 / 0.18 M steps/s -> two-wave register kernel 2.7 / 1.1 M.
+Files: r01_bench_fused_kernel_stats.csv (rocprofv3 --stats), r01_bench_fused_pmc_summary.json (per-launch counter means; bench.py
+reads FETCH_SIZE / WRITE_SIZE from it for `roofline.traffic`), r01_bench_fused_under_rocprof.json (bench line of the traced run),
+r01_bench_default.json (plain `python bench.py`), r01_<tag>_* (other configurations), r01_ubench_issue_cost.txt (instruction
+issue costs of a lone wave), r01_wave_span_T20.txt (per-ego step time vs iteration count), r01_reg_kernel_phase_stamps_T*.txt
+(diagnostic -DJSIM_STAMPS builds: per-phase cycle shares; stamps perturb, read shares not times), r01_v1_lds_* (first kernel).
 """
 open(os.path.join(P, "r01_SUMMARY.txt"), "w").write(txt)
 print(txt)
