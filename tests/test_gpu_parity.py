@@ -281,12 +281,12 @@ def test_plant_and_goal_kernels(pkg, oracle, routes):
     assert np.array_equal(goal.cpu().numpy()[inr], goal_rows[inr, 4].astype(bool))
 
 
-@pytest.mark.parametrize("T", (13, 20, 30))
+@pytest.mark.parametrize("T", (13, 20, 30, 40, 25))
 def test_fused_ticks_equal_single_ticks(pkg, routes, T):
-    """jsim_mpc_run_ticks (one launch, every wavefront runs K ticks of its own ego) must reproduce K x
-    (jsim_mpc_step + jsim_loop_advance) bit for bit: same history, same final state, same respawn count.
-    T = 30 exercises the multi-launch fallback of the same entry point."""
-    B, K = 96, 60
+    """jsim_mpc_run_ticks (one launch, every wavefront -- or pair of wavefronts at T = 30 / 40 -- runs K ticks of its
+    own ego) must reproduce K x (jsim_mpc_step + jsim_loop_advance) bit for bit: same history, same final state, same
+    respawn count.  T = 25 exercises the multi-launch fallback of the same entry point (no fused kernel)."""
+    B, K = 96, (60 if T <= 30 else 30)
     batch = pkg.synth.make_ego_batch(routes, B, T, seed=11, near_end_frac=0.5)
     def make():
         eng = _engine(pkg, routes, batch, T)
@@ -296,7 +296,7 @@ def test_fused_ticks_equal_single_ticks(pkg, routes, T):
     for _ in range(K):
         l1.tick()
     e2, l2 = make()
-    l2.run(25); l2.run(35)
+    l2.run(K // 2 - 5); l2.run(K - (K // 2 - 5))
     torch.cuda.synchronize()
     assert int(l1.tick_counter.item()) == int(l2.tick_counter.item()) == K
     assert torch.equal(l1.hist, l2.hist)
@@ -307,11 +307,12 @@ def test_fused_ticks_equal_single_ticks(pkg, routes, T):
     assert int(l1.n_respawn.item()) == int(l2.n_respawn.item()) > 0
 
 
-@pytest.mark.parametrize("T", (13, 20))
+@pytest.mark.parametrize("T", (13, 20, 30, 40))
 def test_lds_kernel_and_register_kernel_agree(pkg, oracle, routes, T, monkeypatch):
-    """T = 13 / 20 normally run the register-resident kernel; JSIM_FORCE_LDS_KERNEL=1 (read at jsim_mpc_create)
-    routes them through the generic LDS-resident kernel.  Both must match the oracle and each other."""
-    B = 128
+    """T = 13 / 20 / 30 / 40 normally run a register-resident kernel (one or two wavefronts per ego);
+    JSIM_FORCE_LDS_KERNEL=1 (read at jsim_mpc_create) routes them through the generic LDS-resident kernel.  Both must
+    match the oracle and each other."""
+    B = 128 if T <= 20 else 64
     batch = pkg.synth.make_ego_batch(routes, B, T, seed=5, truncate=True, near_end_frac=0.3)
     x0 = torch.from_numpy(batch.x0).cuda()
     e_reg = _engine(pkg, routes, batch, T)
@@ -327,9 +328,9 @@ def test_lds_kernel_and_register_kernel_agree(pkg, oracle, routes, T, monkeypatc
         assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
         assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
         ok = ref["status"] == 0
-        assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-8
-        assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-8
-    assert float((e_reg.oa - e_lds.oa).abs().max()) <= 1e-8
+        assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= (1e-8 if T <= 20 else 1e-7)
+        assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= (1e-8 if T <= 20 else 1e-7)
+    assert float((e_reg.oa - e_lds.oa).abs().max()) <= (1e-8 if T <= 20 else 1e-7)
     assert torch.equal(e_reg.xref, e_lds.xref)
 
 
