@@ -103,3 +103,47 @@ def test_variant_dropin_and_reconfiguration(pkg, oracle, routes):
     assert abs(di2 - ref2["od"][0]) <= 1e-8 and abs(ai2 - ref2["oa"][0]) <= 1e-8
     np.testing.assert_allclose(np.concatenate([mpc.oa, mpc.odelta]), np.concatenate([ref2["oa"], ref2["od"]]), rtol=0, atol=1e-8)
     assert np.abs(np.concatenate([mpc.oa, mpc.odelta]) - u1).max() > 1e-4   # the new weights changed the solution
+
+
+def test_sensitivity_module_constants(pkg):
+    """lib.mpc_sensitivity's import-time constants and its shipped JSON equal the reference's config/mpc_config_sensitivity.json
+    (values recorded here from the reference file: R = (0.1, 0.01), Rd = (10, 10), the rest as mpc_config.json)."""
+    m = pkg.mpc_sensitivity
+    assert (m.NX, m.NU, m.T) == (4, 2, 13) and m.GOAL_DIS == 1.5 and m.STOP_SPEED == 0.1389
+    assert m.MAX_ACCEL == 2.0 and m.MAX_DECEL == -10 and abs(m.MAX_DSTEER - np.deg2rad(30.0)) == 0
+    c = m._load(m.CONFIG_PATH)
+    assert c.R == [0.1, 0.01] and c.Rd == [10.0, 10.0] and c.w_perp == 20.0 and c.w_para == 1.0
+    assert c.Q_v_yaw == [0.0, 0.5] and c.Qf == [1.0, 1.0, 0.0, 0.5] and c.MAX_DECEL == -10.0 and c.T == 13
+
+
+@pytest.mark.gpu
+def test_sensitivity_dropin_rereads_its_json(pkg, oracle, routes, tmp_path, monkeypatch):
+    """main/lib/mpc_sensitivity.py re-reads its JSON inside every solve; the analysis scripts rewrite the file between
+    runs.  Same here: rewrite the file, the next step() solves with the new weights / limits (checked against the
+    oracle), the speed rows use Simulation.MAX_SPEED."""
+    import json
+    m = pkg.mpc_sensitivity
+    raw = json.load(open(m.CONFIG_PATH))
+    path = tmp_path / "mpc_config_sensitivity.json"
+    path.write_text(json.dumps(raw))
+    monkeypatch.setattr(m, "CONFIG_PATH", str(path))
+    r = routes[2].copy()
+    mpc = m.MPC(cx=r[:, 0], cy=r[:, 1], cyaw=r[:, 2].copy(), dl=pkg.synth.DL, car_dimensions=pkg.BicycleModelDimensions())
+    st = pkg.State(x=r[40, 0] + 0.2, y=r[40, 1] - 0.1, yaw=r[40, 2] + 0.05, v=6.0)
+    mpc.target_ind = 36
+    di, ai = mpc.step(st)
+    base = {k: raw[k] for k in ("w_perp", "w_para", "R", "Rd", "Q_v_yaw", "Qf", "MAX_DSTEER", "MAX_ACCEL", "MAX_DECEL")}
+    ref = oracle.mpc_step(oracle.make_params(T=13, config=base), (st.x, st.y, st.yaw, st.v), r[:, 0], r[:, 1], r[:, 2], 36, 30 / 3.6)
+    assert mpc.status == ref["status"] == 0
+    np.testing.assert_allclose(np.concatenate([mpc.oa, mpc.odelta]), np.concatenate([ref["oa"], ref["od"]]), rtol=0, atol=1e-8)
+    u1 = np.concatenate([mpc.oa, mpc.odelta])
+    raw2 = dict(raw, w_perp=5.0, Rd=[0.01, 1.0], MAX_ACCEL=0.5, MAX_DSTEER=10.0)
+    path.write_text(json.dumps(raw2))
+    mpc.oa = mpc.odelta = None
+    mpc.target_ind = 36
+    mpc.step(st)
+    cfg2 = {k: raw2[k] for k in base}
+    ref2 = oracle.mpc_step(oracle.make_params(T=13, config=cfg2), (st.x, st.y, st.yaw, st.v), r[:, 0], r[:, 1], r[:, 2], 36, 30 / 3.6)
+    assert mpc.status == ref2["status"] == 0
+    np.testing.assert_allclose(np.concatenate([mpc.oa, mpc.odelta]), np.concatenate([ref2["oa"], ref2["od"]]), rtol=0, atol=1e-8)
+    assert mpc.oa.max() <= 0.5 + 1e-9 and np.abs(np.concatenate([mpc.oa, mpc.odelta]) - u1).max() > 1e-3
