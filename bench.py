@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--mode", choices=("fused", "graph", "eager"), default="fused",
                     help="fused: K ticks per launch inside the kernel (default); graph: one launch pair per tick "
                          "replayed from a hipGraph; eager: one launch pair per tick from Python")
+    ap.add_argument("--ticks-per-launch", type=int, default=0,
+                    help="fused mode: closed-loop ticks per kernel launch (0 = all K ticks of the timed region in one launch; "
+                         "egos only wait for each other at launch boundaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -105,6 +108,10 @@ def main():
 
     mode = args.mode
     chunk = next(c for c in (50, 25, 20, 10, 5, 4, 2, 1) if K % c == 0)
+    if mode == "fused":
+        chunk = args.ticks_per_launch if args.ticks_per_launch > 0 else K
+        if K % chunk:
+            raise SystemExit(f"--ticks-per-launch {chunk} must divide --steps {K}")
     if mode == "graph":
         loop.capture(chunk)   # (capture runs one extra untimed tick)
     elif mode == "fused":
