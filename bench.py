@@ -181,10 +181,10 @@ def main():
         traffic = None
         pmc_path = os.path.join(REPO, "profiles", "r01_bench_fused_pmc_summary.json")
         if mode == "fused" and T == 20 and B == 256 and os.path.exists(pmc_path):
-            # HBM bytes of one 50-tick launch from the rocprofv3 PMC passes of this same command (profiles/r01_SUMMARY.txt):
+            # HBM bytes of one fused launch from the rocprofv3 PMC passes of this same command (profiles/r01_SUMMARY.txt):
             # FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request), WRITE_SIZE as is, both in KiB; scaled to this chunk
             pmc = json.load(open(pmc_path))
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (ticks_per_launch / 50.0)
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (ticks_per_launch / float(pmc.get("ticks_per_launch", 50)))
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",
             "value": value, "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -50,6 +50,7 @@ for sub in ("trace",):
     for line in open(log):
         if line.startswith('{"metric"'):
             out["bench_line_under_rocprof"] = json.loads(line)
+            out["ticks_per_launch"] = out["bench_line_under_rocprof"]["roofline"]["ticks_per_launch"]
 st = rows("trace", "*kernel_stats.csv")
 out["kernel_stats"] = [r for r in st if "mpc_step" in r.get("Name", "") or "loop_advance" in r.get("Name", "") or "tick_" in r.get("Name", "")]
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
