@@ -170,7 +170,7 @@ __device__ __forceinline__ double wexscan(double v, int lane)
 // the step kernel.  RPL = rows of the n x n factors owned by one lane (n <= 64*RPL).
 // ---------------------------------------------------------------------------------------------------
 enum { TQ_PA = 0, TQ_PB, TQ_PAP, TQ_PBP, TQ_KT, TQ_QXX, TQ_QXY, TQ_QYY, TQ_QV, TQ_QYAW, TQ_QEX, TQ_QEY,
-       TQ_QEV, TQ_QEYAW, TQ_REND, TQ_COUNT };
+       TQ_QEV, TQ_QEYAW, TQ_REND, TQ_ONE, TQ_ZERO /* constant rows for the register kernels' operand tables */, TQ_COUNT };
 
 __host__ __device__ static inline size_t jsim_lds_doubles(int T)
 {
