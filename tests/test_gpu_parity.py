@@ -522,3 +522,31 @@ def test_two_wave_kernel_large_working_sets(pkg, oracle, routes, T):
     assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-6
     assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-6
     assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32)[ok], ref["active_mask"][ok])
+
+
+@pytest.mark.parametrize("T,B", ((30, 2048), (40, 1024)))
+def test_two_wave_kernel_at_scale_and_deterministic(pkg, oracle, routes, T, B):
+    """Two workgroups per CU, many rounds: every ego against the oracle (not just a KKT property), and two runs of the same
+    batch bit-identical -- cross-wave races would show up here as run-to-run differences."""
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=21, truncate=True, near_end_frac=0.2)
+    outs = []
+    for rep in range(2):
+        eng = _engine(pkg, routes, batch, T)
+        eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+        torch.cuda.synchronize()
+        outs.append({k: getattr(eng, k).clone() for k in ("oa", "od", "status", "n_iter", "active_mask", "target_ind", "ox", "oyaw")})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    p = oracle.make_params(T=T)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    ref = oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off,
+                                batch.target_ind, batch.oa, batch.od, n_threads=16)
+    st = outs[0]["status"].cpu().numpy()
+    assert np.array_equal(st, ref["status"])
+    assert np.array_equal(outs[0]["target_ind"].cpu().numpy(), ref["target_ind"])
+    ok = st == 0
+    assert np.abs(outs[0]["oa"].cpu().numpy() - ref["oa"])[ok].max() <= 1e-6
+    assert np.abs(outs[0]["od"].cpu().numpy() - ref["od"])[ok].max() <= 1e-6
+    assert np.array_equal(outs[0]["active_mask"].cpu().numpy().view(np.uint32)[ok], ref["active_mask"][ok])
+    same = outs[0]["n_iter"].cpu().numpy() == ref["n_iter"]
+    assert same.mean() >= 0.9
