@@ -58,11 +58,11 @@ per configuration, from /tmp with TMPDIR=/tmp, `python3 bench.py --steps 100 --w
 """
 txt += para(main, "Default bench: 256 egos, T = 20, fused closed loop (BASELINE.json configs[1])")
 txt += """
-Reading: one wave per CU, ~15k VALU wave-instructions per step at ~5.3 cycles each (tools/ubench/issue_cost.hip: every VALU
+Reading: one wave per CU, ~13k VALU wave-instructions per step at ~5.3 cycles each (tools/ubench/issue_cost.hip: every VALU
 instruction of a lone wave issues in >= 5.3 cycles, a dependent FMA chain in 8.3, FMA->readlane->FMA in 26, a uniform
 branch in ~40, a ds_write_b128 in 25): the path is bound by the issue latency of a single wavefront (SURVEY D6), not by
 HBM and not by MFMA throughput.  The launch time is set by the slowest of the 256 egos (tools/wave_span.py: the mean
-step takes 65.7k + 6.06k * n_iter cycles, the slowest ego averages 21 iterations against a fleet mean of 10.9).
+step takes 55.7k + 6.06k * n_iter cycles, the slowest ego averages 21 iterations against a fleet mean of 10.9).
 """
 for t in tags[1:]:
     p = load(t)
@@ -82,7 +82,10 @@ History of the default bench within round 1 (bench.py, 1 GPU, 256 egos, T = 20):
   + burst LDS reads behind sched barriers                          2.24 M           (18k VALU wave-instr per step)
   + packed 64-bit arg-max / arg-min, pair candidates, L prefetch   2.38 M
   + arithmetic pinned where written (no AGPR round trips)          2.60 M           (15k VALU wave-instr per step)
-Horizons 30 / 40 (4096 egos): LDS-resident kernel 0.84 / 0.18 M steps/s -> two-wave register kernel 2.7 / 1.1 M.
+  + leaner MFMA operand generation, column-oriented factorisation
+    with look-ahead, pipelined forward substitution                2.78 M           (13k VALU wave-instr per step)
+Horizons 30 / 40 (4096 egos): LDS-resident kernel 0.84 / 0.18 M steps/s -> two-wave register kernel 2.9 / 1.3 M.
+Other shapes, same build (r01_other_configs.txt: egos, T, steps/s, ms per tick, mean iterations, fp64 roofline fraction).
 Files: r01_bench_fused_kernel_stats.csv (rocprofv3 --stats), r01_bench_fused_pmc_summary.json (per-launch counter means; bench.py
 reads FETCH_SIZE / WRITE_SIZE from it for `roofline.traffic`), r01_bench_fused_under_rocprof.json (bench line of the traced run),
 r01_bench_default.json (plain `python bench.py`), r01_<tag>_* (other configurations), r01_ubench_issue_cost.txt (instruction
