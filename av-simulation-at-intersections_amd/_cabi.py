@@ -32,7 +32,7 @@ EXPORTS = (
     "jsim_abi_version", "jsim_last_error", "jsim_mpc_create", "jsim_mpc_destroy", "jsim_mpc_set_paths",
     "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance", "jsim_mpc_run_ticks",
     "jsim_loop_set_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
-    "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_loop_obstacles",
+    "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_mpc_set_ego_config", "jsim_loop_obstacles",
     "jsim_mpc_xref_deviation_goal",
 )
 
@@ -84,6 +84,8 @@ def load() -> C.CDLL:
     lib.jsim_mpc_set_speed_cutoff.argtypes = [vp, vp]
     lib.jsim_mpc_update_cfg.restype = C.c_int
     lib.jsim_mpc_update_cfg.argtypes = [vp, C.POINTER(JsimCfg)]
+    lib.jsim_mpc_set_ego_config.restype = C.c_int
+    lib.jsim_mpc_set_ego_config.argtypes = [vp, vp]
     lib.jsim_loop_obstacles.restype = C.c_int
     lib.jsim_loop_obstacles.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     lib.jsim_mpc_run_ticks.restype = C.c_int

@@ -132,6 +132,33 @@ class BatchedMPC:
         _cabi.check(self.lib.jsim_mpc_update_cfg(self._ctx, C.byref(cfg)), self._ctx, "jsim_mpc_update_cfg")
         self.config, self._cfg = config, cfg
 
+    EGO_CFG_DOUBLES = 16
+
+    def set_ego_configs(self, configs):
+        """Per-ego weights and limits (jsim_mpc_set_ego_config): `configs` is a sequence of B MPCConfig objects -- e.g. the
+        parameter sets of a sensitivity sweep (main/scenarios/mpc_sensitivity_analysis*.py), solved as ONE batch -- or an
+        array [B, 16] in the layout of include/jsim_mpc.h, or None to go back to the context's configuration.
+        T, dt, dl, L, R_end, the speed limits and the goal test stay those of the engine."""
+        if configs is None:
+            self._pe = None
+            _cabi.check(self.lib.jsim_mpc_set_ego_config(self._ctx, None), self._ctx, "jsim_mpc_set_ego_config")
+            return
+        if isinstance(configs, (np.ndarray, torch.Tensor)):
+            arr = configs if isinstance(configs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(configs, dtype=np.float64))
+        else:
+            rows = []
+            for c in configs:
+                if c.T != self.T:
+                    raise ValueError("per-ego configurations share the engine's horizon")
+                rows.append([c.w_perp, c.w_para, c.R[0], c.R[1], c.Rd[0], c.Rd[1], c.Q_v_yaw[0], c.Q_v_yaw[1],
+                             c.Qf[0], c.Qf[1], c.Qf[2], c.Qf[3], c.max_dsteer_rad, c.MAX_ACCEL, c.MAX_DECEL, 0.0])
+            arr = torch.tensor(rows, dtype=torch.float64)
+        if tuple(arr.shape) != (self.B, self.EGO_CFG_DOUBLES):
+            raise ValueError(f"need [{self.B}, {self.EGO_CFG_DOUBLES}] per-ego parameters, got {tuple(arr.shape)}")
+        self._pe = arr.to(device=self.device, dtype=torch.float64).contiguous()
+        _cabi.check(self.lib.jsim_mpc_set_ego_config(self._ctx, C.c_void_p(self._pe.data_ptr())), self._ctx,
+                    "jsim_mpc_set_ego_config")
+
     def load_state(self, target_ind=None, oa=None, od=None, path_len=None):
         """Overwrite the resident controller state (host arrays or tensors): remembered path index, warm
         start, truncated path lengths."""

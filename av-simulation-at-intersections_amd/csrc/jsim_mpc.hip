@@ -71,6 +71,7 @@ struct KP {
     const double *pyaw;
     const double *pcv;   // per-point speed reference of the mpc_with_speed variant, or NULL (xref[2] = 0, mpc.py:107)
     const int *cv_cut;   // [B] index from which that reference is zeroed, or NULL
+    const double *pe;    // [B][JSIM_EGO_CFG_DOUBLES] per-ego weights / limits (jsim_mpc_set_ego_config), or NULL
     const long long *poff;
     const double *x0;
     const int *path_id;
@@ -88,6 +89,16 @@ struct KP {
     int dbg_max_gi;     // diagnostic builds only (-DJSIM_STAMPS / -DJSIM_SPAN, env JSIM_DEBUG_MAX_GI): stop the active-set loop after this many
                         // outer iterations (results are then NOT the optimum); -1 = off
 };
+
+// per-ego weights / limits over the launch constants (uniform loads: the row depends on the workgroup only)
+template <class KPT>
+__device__ __forceinline__ void jsim_apply_ego_cfg(KPT &P, const double *pe, int ego, int T, double dt)
+{
+    const double *w = pe + (size_t)ego * JSIM_EGO_CFG_DOUBLES;
+    P.w_perp = w[0]; P.w_para = w[1]; P.R0 = w[2]; P.R1 = w[3]; P.Rd0 = w[4]; P.Rd1 = w[5]; P.Qv = w[6]; P.Qyaw = w[7];
+    P.Qf0 = w[8] * T; P.Qf1 = w[9] * T; P.Qf2 = w[10] * T; P.Qf3 = w[11] * T;
+    P.dmax = w[12] * dt; P.amax = w[13]; P.amin = w[14];
+}
 
 // ---------------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
@@ -181,8 +192,10 @@ __host__ __device__ static inline size_t jsim_lds_doubles(int T)
 }
 
 template <int RPL>
-__global__ __launch_bounds__(64) void mpc_step_kernel(const KP P)
+__global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 {
+    KP P = Pin;
+    if (Pin.pe && (int)blockIdx.x < Pin.B) jsim_apply_ego_cfg(P, Pin.pe, blockIdx.x, Pin.T, Pin.dt);
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int ego = blockIdx.x;
@@ -974,6 +987,7 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K)
 struct PlantP {
     int B, T;
     double dt, L, smax, vmax, vmin, max_decel;
+    const double *pe; // per-ego configuration (MAX_DECEL at [14]) or NULL
 };
 
 __global__ __launch_bounds__(256) void plant_step_kernel(PlantP P, double *x0, const double *oa, const double *od,
@@ -983,7 +997,7 @@ __global__ __launch_bounds__(256) void plant_step_kernel(PlantP P, double *x0, c
     if (b >= P.B) return;
     double di = di_ai[2 * b], ai;
     if (status[b] == JSIM_OK) { di = od[(size_t)b * P.T]; ai = oa[(size_t)b * P.T]; }
-    else ai = P.max_decel;
+    else ai = P.pe ? P.pe[(size_t)b * JSIM_EGO_CFG_DOUBLES + 14] : P.max_decel;
     di_ai[2 * b] = di;
     di_ai[2 * b + 1] = ai;
     double x = x0[4 * b], y = x0[4 * b + 1], v = x0[4 * b + 2], th = x0[4 * b + 3];
@@ -1005,6 +1019,7 @@ struct LoopP {
     double dt, L, smax, vmax, vmin, max_decel, goal_dis, stop_speed;
     const double2 *pxy;
     const long long *poff;
+    const double *pe; // per-ego configuration (MAX_DECEL at [14]) or NULL
 };
 
 __global__ __launch_bounds__(256) void loop_advance_kernel(LoopP P, double *x0, double *oa, double *od,
@@ -1018,7 +1033,7 @@ __global__ __launch_bounds__(256) void loop_advance_kernel(LoopP P, double *x0, 
     if (b >= P.B) return;
     double di = di_ai[2 * b], ai;
     if (status[b] == JSIM_OK) { di = od[(size_t)b * P.T]; ai = oa[(size_t)b * P.T]; }
-    else ai = P.max_decel;
+    else ai = P.pe ? P.pe[(size_t)b * JSIM_EGO_CFG_DOUBLES + 14] : P.max_decel;
     di_ai[2 * b] = di;
     di_ai[2 * b + 1] = ai;
     if (hist) {
@@ -1116,6 +1131,7 @@ struct jsim_ctx {
     double *d_pcv;          // speed reference per path point (mpc_with_speed variant) or NULL
     const int *cv_cut;      // caller-owned device array [B] or NULL
     size_t lds_bytes;
+    const double *d_pe; // per-ego weights / limits (caller-owned device array) or NULL
     int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
     int dbg_max_gi;
     long long *dbg_clk; // diagnostic builds only
@@ -1267,7 +1283,7 @@ static void fill_kp(const jsim_ctx *ctx, int32_t B, KP &P)
     P.dmax = c.max_dsteer * c.dt; P.amax = c.max_accel; P.amin = c.max_decel; P.smax = c.max_steer;
     P.vmax_plant = c.max_speed; P.vmin = c.min_speed; P.vref_min = c.min_ref_speed;
     P.pxy = ctx->d_pxy; P.pyaw = ctx->d_pyaw; P.poff = ctx->d_poff;
-    P.pcv = ctx->d_pcv; P.cv_cut = ctx->cv_cut;
+    P.pcv = ctx->d_pcv; P.cv_cut = ctx->cv_cut; P.pe = ctx->d_pe;
 }
 
 static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, const int32_t *path_len,
@@ -1330,7 +1346,7 @@ extern "C" int jsim_plant_step(jsim_ctx *ctx, int32_t B, double *x0, const doubl
     if (B == 0) return 0;
     if (!x0 || !oa || !od || !status || !di_ai) return fail(ctx, -22, "jsim_plant_step: null device pointer");
     const jsim_cfg &c = ctx->cfg;
-    PlantP P = {B, c.T, c.dt, c.L, c.max_steer, c.max_speed, c.min_speed, c.max_decel};
+    PlantP P = {B, c.T, c.dt, c.L, c.max_steer, c.max_speed, c.min_speed, c.max_decel, ctx->d_pe};
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, x0, oa, od, status, di_ai);
     HIP_TRY(ctx, hipGetLastError());
@@ -1370,7 +1386,7 @@ extern "C" int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *o
     if (!ctx->d_pxy) return fail(ctx, -22, "jsim_loop_advance: no paths set");
     const jsim_cfg &c = ctx->cfg;
     LoopP P = {B, c.T, max_age > 0 ? max_age : 0x7fffffff, c.dt, c.L, c.max_steer, c.max_speed, c.min_speed,
-               c.max_decel, c.goal_dis, c.stop_speed, ctx->d_pxy, ctx->d_poff};
+               c.max_decel, c.goal_dis, c.stop_speed, ctx->d_pxy, ctx->d_poff, ctx->d_pe};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loop_advance_kernel, dim3((B + 255) / 256), dim3(256), 0, s, P, x0, oa, od, status, di_ai,
                        (long long *)target_ind, path_id, path_len, x0_spawn, (const long long *)target_spawn, age, hist,
@@ -1518,6 +1534,13 @@ extern "C" int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg)
         !(cfg->R_end[1] > 0))
         return fail(ctx, -22, "jsim_mpc_update_cfg: dt, dl, L, R, R_end must be positive");
     ctx->cfg = *cfg;
+    return 0;
+}
+
+extern "C" int jsim_mpc_set_ego_config(jsim_ctx *ctx, const double *cfg)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_ego_config: null ctx");
+    ctx->d_pe = cfg;
     return 0;
 }
 

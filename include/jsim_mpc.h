@@ -129,6 +129,15 @@ int jsim_mpc_set_path_speed(jsim_ctx *ctx, const double *cv);
 int jsim_mpc_set_speed_cutoff(jsim_ctx *ctx, const int32_t *cv_cut);
 int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg);
 
+/* Per-ego weights and limits: a whole sensitivity sweep (main/scenarios/mpc_sensitivity_analysis*.py run the loop once per
+ * parameter set, rewriting config/mpc_config_sensitivity.json in between) as ONE batch -- ego b solves with its own row of
+ * cfg, a caller-owned DEVICE array [B][JSIM_EGO_CFG_DOUBLES] in the JSON's own units:
+ *   { w_perp, w_para, R[0], R[1], Rd[0], Rd[1], Q_v_yaw[0], Q_v_yaw[1], Qf[0..3] (unscaled; x T inside, mpc.py:28),
+ *     MAX_DSTEER [rad/s], MAX_ACCEL, MAX_DECEL, reserved }.
+ * Everything else (T, dt, dl, L, R_end, speed limits, goal test) stays with the context's jsim_cfg.  NULL switches back. */
+#define JSIM_EGO_CFG_DOUBLES 16
+int jsim_mpc_set_ego_config(jsim_ctx *ctx, const double *cfg);
+
 /* ---- the loop glue that produces the truncated path, main/scenarios/mpc_intersection.py:104-140 ----
  * jsim_loop_set_geometry: the car's two collision circles (offsets of their centres from the rear axle along the body
  *   axis, radius) = car_dimensions.circle_centers / .radius, main/lib/car_dimensions.py:62-79; precomputes the circle

@@ -147,3 +147,56 @@ def test_sensitivity_dropin_rereads_its_json(pkg, oracle, routes, tmp_path, monk
     assert mpc.status == ref2["status"] == 0
     np.testing.assert_allclose(np.concatenate([mpc.oa, mpc.odelta]), np.concatenate([ref2["oa"], ref2["od"]]), rtol=0, atol=1e-8)
     assert mpc.oa.max() <= 0.5 + 1e-9 and np.abs(np.concatenate([mpc.oa, mpc.odelta]) - u1).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", (20, 30, 25))
+def test_per_ego_weights_one_batch(pkg, oracle, routes, T):
+    """A sensitivity sweep as one launch: every ego of the batch carries its own weights and limits
+    (jsim_mpc_set_ego_config).  T = 20 / 30 / 25 = one-wave, two-wave and LDS kernels.  Each ego against the oracle run
+    with that ego's parameters; switching the table off restores the engine's configuration."""
+    from dataclasses import replace
+    B = 48
+    rng = np.random.default_rng(17)
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=4, truncate=True, near_end_frac=0.2)
+    base = pkg.MPCConfig.from_json()
+    cfgs = [replace(base, T=T, w_perp=float(rng.uniform(5, 40)), w_para=float(rng.uniform(0.5, 3)),
+                    R=[float(rng.uniform(0.005, 0.2)), float(rng.uniform(0.005, 0.05))],
+                    Rd=[float(rng.uniform(0.005, 10)), float(rng.uniform(0.5, 10))],
+                    Q_v_yaw=[float(rng.choice([0.0, 2.0])), float(rng.uniform(0.1, 1.0))],
+                    Qf=[float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)), 0.0, float(rng.uniform(0.2, 1.0))],
+                    MAX_DSTEER=float(rng.uniform(10, 60)), MAX_ACCEL=float(rng.uniform(0.5, 3)),
+                    MAX_DECEL=float(-rng.uniform(3, 10))) for _ in range(B)]
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    x0 = torch.from_numpy(batch.x0).to(eng.device)
+    eng.solve(x0)
+    plain = (eng.oa.clone(), eng.od.clone())
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    eng.set_ego_configs(cfgs)
+    eng.solve(x0)
+    torch.cuda.synchronize()
+    oa, od, st = eng.oa.cpu().numpy(), eng.od.cpu().numpy(), eng.status.cpu().numpy()
+    am = eng.active_mask.cpu().numpy().view(np.uint32)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    n_ok = 0
+    for b in range(B):
+        c = cfgs[b]
+        p = oracle.make_params(T=T, config={"w_perp": c.w_perp, "w_para": c.w_para, "R": c.R, "Rd": c.Rd, "Q_v_yaw": c.Q_v_yaw,
+                                            "Qf": c.Qf, "MAX_DSTEER": c.MAX_DSTEER, "MAX_ACCEL": c.MAX_ACCEL, "MAX_DECEL": c.MAX_DECEL})
+        o = off[batch.path_id[b]]
+        n = batch.path_len[b]
+        r = oracle.mpc_step(p, (batch.x0[b, 0], batch.x0[b, 1], batch.x0[b, 3], batch.x0[b, 2]), cx[o:o + n], cy[o:o + n],
+                            cyaw[o:o + n], int(batch.target_ind[b]), batch.speed[b], oa=batch.oa[b], od=batch.od[b])
+        assert st[b] == r["status"], b
+        if st[b] == 0:
+            n_ok += 1
+            assert np.abs(oa[b] - r["oa"]).max() <= 1e-7 and np.abs(od[b] - r["od"]).max() <= 1e-7, b
+            assert np.array_equal(am[b], np.asarray(r["active_mask"], dtype=np.uint32)), b
+            assert oa[b].max() <= c.MAX_ACCEL + 1e-9 and oa[b].min() >= c.MAX_DECEL - 1e-9
+    assert n_ok >= B - 6
+    assert float((eng.oa - plain[0]).abs().max()) > 1e-2       # the table changed the solutions
+    eng.set_ego_configs(None)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    eng.solve(x0)
+    assert torch.equal(eng.oa, plain[0]) and torch.equal(eng.od, plain[1])
