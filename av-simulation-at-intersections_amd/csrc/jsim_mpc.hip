@@ -64,6 +64,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct KP {
     int T, n, ld, B;
+    int pass; // 0: first linearisation; k >= 1: re-linearisation pass k of MAX_ITER (mpc.py:231): skips egos that failed,
+              // takes the travel distances from the previous pass's predicted speeds (P.ov) and accumulates n_iter
     double dt, dl, L, w_perp, w_para;
     double R0, R1, Rd0, Rd1, Qv, Qyaw, Qf0, Qf1, Qf2, Qf3, Re0, Re1; // Qf* already multiplied by T
     double dmax, amax, amin, smax, vmax_plant, vmin, vref_min;
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
     const int lane = threadIdx.x;
     const int ego = blockIdx.x;
     if (ego >= P.B) return;
+    if (P.pass > 0 && P.status[ego] != JSIM_OK) return; // failed in an earlier pass of this step: the failure stands
+    const int it_base = (P.pass > 0 && P.n_iter) ? P.n_iter[ego] : 0;
     const int T = P.T, n = P.n, ld = P.ld, tp = T + 2;
     const int MW = (8 * T + 31) >> 5;
 
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
     if (status != JSIM_OK) { // reference raises: nothing is updated
         if (lane == 0) {
             P.status[ego] = status;
-            if (P.n_iter) P.n_iter[ego] = 0;
+            if (P.n_iter) P.n_iter[ego] = it_base;
         }
         return;
     }
@@ -282,8 +286,15 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
         double vref = (P.vref_min > sv) ? P.vref_min : sv; // python max(state.v, 10/3.6)
         double cstep = fabs(vref) * dt;
         double trav = cstep;
-        for (int j = 1; j <= T; ++j)
-            if (j <= tl_idx) trav = trav + cstep; // np.cumsum: sequential
+        if (P.pass == 0) {
+            for (int j = 1; j <= T; ++j)
+                if (j <= tl_idx) trav = trav + cstep; // np.cumsum: sequential
+        } else { // ov = the previous pass's predicted speeds (mpc.py:232,101)
+            const double *ovp = P.ov + (size_t)ego * (T + 1);
+            trav = fabs(ovp[0]) * dt;
+            for (int j = 1; j <= T; ++j)
+                if (j <= tl_idx) trav = trav + fabs(ovp[j]) * dt;
+        }
         ik = (long long)rint(trav / P.dl) + tind;
         if (ik > M - 1) ik = M - 1;
         double2 pr = P.pxy[off + ik];
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
         if (lane == 0) {
             P.status[ego] = status;
             P.target_ind[ego] = tind;
-            if (P.n_iter) P.n_iter[ego] = 0;
+            if (P.n_iter) P.n_iter[ego] = it_base;
         }
         return;
     }
@@ -909,7 +920,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
         if (lane == 0) {
             P.status[ego] = status;
             P.target_ind[ego] = tind;
-            if (P.n_iter) P.n_iter[ego] = iters;
+            if (P.n_iter) P.n_iter[ego] = it_base + iters;
         }
         return;
     }
@@ -952,7 +963,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
     if (lane == 0) {
         P.status[ego] = JSIM_OK;
         P.target_ind[ego] = tind;
-        if (P.n_iter) P.n_iter[ego] = iters;
+        if (P.n_iter) P.n_iter[ego] = it_base + iters;
     }
     STAMP(11);
 }
@@ -1166,7 +1177,7 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
 {
     if (!cfg || !out) return fail(nullptr, -22, "jsim_mpc_create: null argument");
     if (cfg->T < 1 || cfg->T > JSIM_MAX_T) return fail(nullptr, -22, "jsim_mpc_create: T=%d outside [1, %d]", cfg->T, JSIM_MAX_T);
-    if (cfg->max_iter != 1) return fail(nullptr, -22, "jsim_mpc_create: MAX_ITER=%d unsupported (stock value 1 only)", cfg->max_iter);
+    if (cfg->max_iter < 1 || cfg->max_iter > 16) return fail(nullptr, -22, "jsim_mpc_create: MAX_ITER=%d (1..16)", cfg->max_iter);
     if (!(cfg->dt > 0) || !(cfg->dl > 0) || !(cfg->L > 0)) return fail(nullptr, -22, "jsim_mpc_create: dt, dl, L must be positive");
     if (!(cfg->R[0] > 0) || !(cfg->R[1] > 0) || !(cfg->R_end[0] > 0) || !(cfg->R_end[1] > 0))
         return fail(nullptr, -22, "jsim_mpc_create: R / R_end must be positive (strict convexity)");
@@ -1312,9 +1323,13 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
     TickP K;
     memset(&K, 0, sizeof(K));
     K.n_ticks = 1; // plain MPC.step: one tick, no plant/bookkeeping
-    if (ctx->use_reg_kernel) launch_reg(c.T, B, s, P, K);
-    else if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
-    else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
+    if (c.max_iter > 1 && !ov) return fail(ctx, -22, "jsim_mpc_step: MAX_ITER=%d needs the ov buffer (the next pass's travel distances)", c.max_iter);
+    for (int pass = 0; pass < c.max_iter; ++pass) { // _iterative_linear_mpc_control, main/lib/mpc.py:231-236: one launch per pass
+        P.pass = pass;
+        if (ctx->use_reg_kernel) launch_reg(c.T, B, s, P, K);
+        else if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
+        else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -1423,8 +1438,8 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_run_ticks: jsim_mpc_set_paths has not been called");
     const jsim_cfg &c = ctx->cfg;
     hipStream_t s = (hipStream_t)stream;
-    if (!ctx->use_reg_kernel) {
-        // horizons without the fused register kernel: the same ticks as separate launches
+    if (!ctx->use_reg_kernel || c.max_iter > 1) {
+        // horizons without the fused register kernel, or several linearisation passes per step: the same ticks as separate launches
         for (int k = 0; k < n_ticks; ++k) {
             int rc = launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref,
                                  active_mask, status, n_iter, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
@@ -1529,7 +1544,7 @@ extern "C" int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg)
 {
     if (!ctx || !cfg) return fail(ctx, -22, "jsim_mpc_update_cfg: null argument");
     if (cfg->T != ctx->cfg.T) return fail(ctx, -22, "jsim_mpc_update_cfg: the horizon cannot change (T=%d -> %d)", ctx->cfg.T, cfg->T);
-    if (cfg->max_iter != 1) return fail(ctx, -22, "jsim_mpc_update_cfg: MAX_ITER=%d unsupported", cfg->max_iter);
+    if (cfg->max_iter < 1 || cfg->max_iter > 16) return fail(ctx, -22, "jsim_mpc_update_cfg: MAX_ITER=%d (1..16)", cfg->max_iter);
     if (!(cfg->dt > 0) || !(cfg->dl > 0) || !(cfg->L > 0) || !(cfg->R[0] > 0) || !(cfg->R[1] > 0) || !(cfg->R_end[0] > 0) ||
         !(cfg->R_end[1] > 0))
         return fail(ctx, -22, "jsim_mpc_update_cfg: dt, dl, L, R, R_end must be positive");

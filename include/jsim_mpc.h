@@ -58,7 +58,7 @@ extern "C" {
 
 typedef struct jsim_cfg {
     int32_t T;        /* horizon; 1 <= T <= JSIM_MAX_T (stock 13) */
-    int32_t max_iter; /* MAX_ITER; only 1 (the stock value) is supported */
+    int32_t max_iter; /* MAX_ITER (1..16; stock value 1): linearisation passes per step, main/lib/mpc.py:231 */
     double dt, dl, L;
     double w_perp, w_para;
     double R[2], Rd[2], Q_v_yaw[2];

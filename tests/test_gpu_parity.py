@@ -550,3 +550,45 @@ def test_two_wave_kernel_at_scale_and_deterministic(pkg, oracle, routes, T, B):
     assert np.array_equal(outs[0]["active_mask"].cpu().numpy().view(np.uint32)[ok], ref["active_mask"][ok])
     same = outs[0]["n_iter"].cpu().numpy() == ref["n_iter"]
     assert same.mean() >= 0.9
+
+
+@pytest.mark.parametrize("T", (13, 20, 30, 25))
+def test_max_iter_relinearisation_passes(pkg, oracle, routes, T):
+    """MAX_ITER > 1 (main/lib/mpc.py:231-236): every pass re-selects the reference window with the previous pass's
+    predicted speeds, rolls out the previous solution and solves again.  Three passes against the oracle's three passes;
+    a closed loop with two passes per tick through jsim_mpc_run_ticks equals the same ticks one by one."""
+    from dataclasses import replace
+    B = 96 if T <= 20 else 48
+    cfg = replace(pkg.MPCConfig.from_json(), T=T, MAX_ITER=3)
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=8, truncate=True, near_end_frac=0.2)
+    batch.x0[3, 2] = 9.9      # infeasible from the first pass on
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False, config=cfg)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+    torch.cuda.synchronize()
+    p, ref = _oracle_batch(oracle, pkg, routes, batch, T, config={"MAX_ITER": 3})
+    p1, ref1 = _oracle_batch(oracle, pkg, routes, batch, T)
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st, ref["status"]) and st[3] == 1
+    assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy()[st == 0], ref["xref"][st == 0])
+    ok = st == 0
+    assert np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max() <= 1e-7
+    assert np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max() <= 1e-7
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32)[ok], ref["active_mask"][ok])
+    assert (eng.n_iter.cpu().numpy() == ref["n_iter"]).mean() >= 0.9           # summed over the passes
+    assert np.abs(ref["oa"] - ref1["oa"])[ok].max() > 1e-3                     # the extra passes matter
+    # closed loop, two passes per tick: K fused-entry ticks == K single ticks
+    cfg2 = replace(cfg, MAX_ITER=2)
+    K = 12
+    def make():
+        e = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False, config=cfg2)
+        e.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+        return e, pkg.ClosedLoop(e, torch.from_numpy(batch.x0).to(e.device), hist_cap=K, max_age=40)
+    e1, l1 = make()
+    for _ in range(K):
+        l1.tick()
+    e2, l2 = make()
+    l2.run(K)
+    torch.cuda.synchronize()
+    assert torch.equal(l1.hist, l2.hist) and torch.equal(l1.x0, l2.x0) and torch.equal(e1.n_iter, e2.n_iter)
