@@ -12,7 +12,12 @@ LIB = os.path.join(_HERE, "libjsim_mpc.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # S1-S3 follow numpy's operation order; fma() is explicit where wanted
-               "-fno-fast-math"]
+               "-fno-fast-math",
+               # Spills of these 400-500-register kernels go to scratch, not to "free" AGPRs: with the default
+               # (spill-vgpr-to-agpr on) one instantiation of the two-wave kernel was miscompiled -- correct Hessian and
+               # gradient, wrong active-set iterations, right again with this option, with machine sinking disabled, or
+               # with any instrumentation of the loop.  Register counts and speed are the same either way.
+               "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
 
 
 def _hipcc() -> str:
