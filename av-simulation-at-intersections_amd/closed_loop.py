@@ -94,10 +94,20 @@ def car_circles(L: float = 2.86, width: float = 2.0, extra_length: float = 0.64)
 class PreTick:
     """The loop glue ahead of MPC.step (main/scenarios/mpc_intersection.py:104-143) for the whole batch: progress index,
     ego-path resampling, obstacle prediction, collision check, cut-off -> writes the engine's `path_len`, i.e. the batched
-    `mpc.set_trajectory_fromarray(trajectory_full[:cutoff_idx])`.  Obstacles are shared by all egos of the batch."""
+    `mpc.set_trajectory_fromarray(trajectory_full[:cutoff_idx])`.  Obstacles are shared by all egos of the batch.
+
+    mode = "speed_cutoff" is the glue of main/scenarios/mpc_intersection_new_ref.py (:122-139, FRAME_WINDOW = 20 there): the
+    path is never truncated, the cut-off index goes to the mpc_with_speed controller instead
+    (`mpc.set_trajectory_fromarray(trajectory_full, cutoff_idx=...)`: the speed reference is zeroed from it on) -- the
+    engine must carry a speed reference (`cv`)."""
 
     def __init__(self, engine: BatchedMPC, frame_window: int = 10, time_horizon: float = 7.0, car_width: float = 2.0,
-                 extra_length: float = 0.64):
+                 extra_length: float = 0.64, mode: str = "truncate"):
+        if mode not in ("truncate", "speed_cutoff"):
+            raise ValueError("mode must be 'truncate' or 'speed_cutoff'")
+        if mode == "speed_cutoff" and engine.cv is None:
+            raise ValueError("mode='speed_cutoff' needs an engine with a speed reference (cv)")
+        self.mode = mode
         self.eng = engine
         eng = engine
         self.radius, (c0, c1) = car_circles(eng.L, car_width, extra_length)
@@ -114,6 +124,12 @@ class PreTick:
         self.status = torch.zeros(B, dtype=torch.int32, device=dev)
         self.pred = None
         self.n_obs = 0
+        self.cut = None
+        if mode == "speed_cutoff":
+            self.full_len = eng.path_len.clone()
+            self.cut = eng.path_len.clone()              # = "no cut-off" (the reference's 999)
+            eng.set_speed_cutoff(self.cut)
+            self.cut = eng.cv_cut                        # the buffer the controller reads; updated in place every tick
         self.predict(torch.zeros(0, 6, dtype=torch.float64, device=dev))
 
     def predict(self, obst: torch.Tensor):
@@ -135,11 +151,13 @@ class PreTick:
         dbg_idx = dbg_n = None
         if debug is not None:
             dbg_idx, dbg_n = debug["res_idx"], debug["n_res"]
+        out = eng.path_len if self.mode == "truncate" else self.cut
         _cabi.check(eng.lib.jsim_loop_pre_tick(
-            eng._ctx, eng.B, _ptr(x0), _ptr(eng.path_id), _ptr(self.traj_idx), _ptr(self.prev_len), _ptr(eng.path_len),
+            eng._ctx, eng.B, _ptr(x0), _ptr(eng.path_id), _ptr(self.traj_idx), _ptr(self.prev_len), _ptr(out),
             _ptr(self.col_flag), _ptr(self.col_xy), _ptr(self.first_idx), _ptr(self.status), self.frame_window,
             self.margin, _ptr(dbg_idx), _ptr(dbg_n), eng._stream()), eng._ctx, "jsim_loop_pre_tick")
-        self.prev_len.copy_(eng.path_len)
+        # the previous tmp_trajectory: the truncated path, or always the full one (mpc_intersection_new_ref.py:131)
+        self.prev_len.copy_(eng.path_len if self.mode == "truncate" else self.full_len)
 
 
 class ScriptedObstacles:
@@ -179,9 +197,10 @@ class ScenarioLoop:
     obstacle get() -> prediction -> progress index / resample / collision / cut-off -> MPC.step -> plant, history, goal ->
     obstacle step()."""
 
-    def __init__(self, engine: BatchedMPC, x0: torch.Tensor, obstacle_specs, hist_cap: int = 0, max_age: int = 0):
+    def __init__(self, engine: BatchedMPC, x0: torch.Tensor, obstacle_specs, hist_cap: int = 0, max_age: int = 0,
+                 frame_window: int = 10, mode: str = "truncate"):
         self.loop = ClosedLoop(engine, x0, hist_cap=hist_cap, max_age=max_age)
-        self.pre = PreTick(engine)
+        self.pre = PreTick(engine, frame_window=frame_window, mode=mode)
         self.obst = ScriptedObstacles(engine, obstacle_specs)
 
     def tick(self):

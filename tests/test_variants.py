@@ -200,3 +200,41 @@ def test_per_ego_weights_one_batch(pkg, oracle, routes, T):
     eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
     eng.solve(x0)
     assert torch.equal(eng.oa, plain[0]) and torch.equal(eng.od, plain[1])
+
+
+@pytest.mark.gpu
+def test_new_ref_loop_glue_speed_cutoff_mode(pkg, routes):
+    """main/scenarios/mpc_intersection_new_ref.py keeps the full path and hands the collision cut-off to mpc_with_speed
+    (cutoff_idx): PreTick(mode="speed_cutoff") writes the same index the truncating glue writes to path_len into the
+    controller's speed cut-off instead, and the solve then sees a zero speed reference from that index on."""
+    T, B = 13, 32
+    m = pkg.mpc_with_speed
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=12, truncate=False, near_end_frac=0.0)
+    cvs = [np.full(len(r), m.MAX_SPEED) for r in routes]
+    x0 = torch.from_numpy(batch.x0).cuda()
+    # obstacles parked on the first ego's path ahead of it, so that several egos see a collision
+    r0 = routes[int(batch.path_id[0])]
+    j = min(int(batch.target_ind[0]) + 150, len(r0) - 1)
+    obst = torch.tensor([[r0[j, 0], r0[j, 1], 0.0, r0[j, 2] + 1.2, 0.0, 0.0],
+                         [r0[j, 0] + 1.0, r0[j, 1] - 2.0, 2.0, r0[j, 2] - 1.0, 0.0, 0.0]], dtype=torch.float64, device="cuda")
+    def engine():
+        e = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False, config=m.config, cv=cvs)
+        e.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+        return e
+    ea, eb = engine(), engine()
+    pa = pkg.PreTick(ea, frame_window=20)
+    pb = pkg.PreTick(eb, frame_window=20, mode="speed_cutoff")
+    for pre in (pa, pb):
+        pre.predict(obst)
+        pre.run(x0)
+    torch.cuda.synchronize()
+    assert int(pa.col_flag.sum().item()) >= 1                                    # somebody is cut off
+    assert torch.equal(pb.cut, ea.path_len) and torch.equal(pa.traj_idx, pb.traj_idx)
+    assert torch.equal(eb.path_len, torch.from_numpy(batch.path_len).cuda())      # the path itself stays whole
+    eb.solve(x0)
+    torch.cuda.synchronize()
+    ridx_zero = (eb.xref[:, 2] == 0).cpu().numpy()
+    cut = pb.cut.cpu().numpy()
+    assert ridx_zero[cut < batch.path_len].any() and not ridx_zero[(cut >= batch.path_len)].any()
+    with pytest.raises(ValueError):
+        pkg.PreTick(pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, smooth=False), mode="speed_cutoff")
