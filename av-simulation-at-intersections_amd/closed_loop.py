@@ -161,27 +161,37 @@ class PreTick:
 
 
 class ScriptedObstacles:
-    """Device-resident `MovingObstacleTIntersection` vehicles (main/lib/moving_obstacles.py:166-232).
-    specs: list of dicts(direction=+-1, turning=bool, speed=float, offset=float|None) like the scenario builds them
-    (main/scenarios/mpc_intersection.py:46-49)."""
+    """Device-resident scripted obstacle vehicles of main/lib/moving_obstacles.py.
+    specs: list of dicts like the scenarios build them (main/scenarios/mpc_intersection.py:46-49):
+      kind="t_intersection" (default) | "roundabout": direction=+-1, turning=bool, speed=float, offset=float|None
+      kind="arterial": x_init, y_init, speed, initial_speed, offset=float|None   (drives straight up)"""
+
+    KINDS = {"t_intersection": 0.0, "roundabout": 1.0, "arterial": 2.0}
 
     def __init__(self, engine: BatchedMPC, specs, dt: Optional[float] = None):
         self.eng = engine
         dt = engine.dt if dt is None else dt
         st, pr = [], []
         for s in specs:
-            d = 1.0 if s.get("direction", 1) >= 0 else -1.0
+            kind = s.get("kind", "t_intersection")
+            if kind not in self.KINDS:
+                raise ValueError(f"unknown obstacle kind {kind!r}")
             off = s.get("offset", None)
             off = float(off) if (off is not None and off > 0) else 0.0
+            if kind == "arterial":
+                st.append([float(s["x_init"]), float(s["y_init"]), math.pi / 2, 0.0])
+                pr.append([1.0, 0.0, float(s["speed"]), off, 0.0, float(dt), self.KINDS[kind], float(s["initial_speed"])])
+                continue
+            d = 1.0 if s.get("direction", 1) >= 0 else -1.0
             if d > 0:
                 st.append([-30.0, -3.0, 0.0, 0.0]); x_turn = -10.0
             else:
                 st.append([30.0, 3.0, math.pi, 0.0]); x_turn = 12.0
-            pr.append([d, 1.0 if s.get("turning", False) else 0.0, float(s["speed"]), off, x_turn, float(dt)])
+            pr.append([d, 1.0 if s.get("turning", False) else 0.0, float(s["speed"]), off, x_turn, float(dt), self.KINDS[kind], 0.0])
         dev = engine.device
         self.n = len(specs)
         self.state = torch.tensor(st, dtype=torch.float64, device=dev).reshape(self.n, 4)
-        self.param = torch.tensor(pr, dtype=torch.float64, device=dev).reshape(self.n, 6)
+        self.param = torch.tensor(pr, dtype=torch.float64, device=dev).reshape(self.n, 8)
         self.get_buf = torch.zeros(max(self.n, 1), 6, dtype=torch.float64, device=dev)
 
     def get(self, step: bool = False) -> torch.Tensor:

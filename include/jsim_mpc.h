@@ -153,10 +153,11 @@ int jsim_mpc_set_ego_config(jsim_ctx *ctx, const double *cfg);
  *   exactly what jsim_mpc_step takes.  prev_path_len [B]: previous tick's path_len, -1 before the first tick.
  *   status: 0 ok, 2 nearest-index anomaly, 4 resampled path longer than the kernel's 320-point table. */
 int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius);
-/* Scripted obstacle vehicles (MovingObstacleTIntersection, main/lib/moving_obstacles.py:166-232): state [n_obs][4] =
- * (xc, yc, theta, counter) in/out, param [n_obs][6] = (direction +-1, turning 0/1, speed, offset seconds (<= 0: none), x_turn,
- * dt).  Writes the `get()` tuples (x, y, v, yaw, 0, steer) of the CURRENT state to `get` (may be NULL) -- the input of
- * jsim_loop_predict_obstacles -- and, when do_step != 0, advances the state by one `step()` (:225-228). */
+/* Scripted obstacle vehicles of main/lib/moving_obstacles.py -- MovingObstacleTIntersection (:166-232, kind 0),
+ * MovingObstacleRoundabout (:28-124, kind 1), MovingObstacleArterial (:126-164, kind 2): state [n_obs][4] = (xc, yc, theta,
+ * counter) in/out, param [n_obs][8] = (direction +-1, turning 0/1, speed, offset seconds (<= 0: none), x_turn, dt, kind,
+ * initial_speed).  Writes the `get()` tuples (x, y, v, yaw, 0, steer) of the CURRENT state to `get` (may be NULL) -- the input
+ * of jsim_loop_predict_obstacles -- and, when do_step != 0, advances the state by one `step()`. */
 int jsim_loop_obstacles(jsim_ctx *ctx, int32_t n_obs, double *state, const double *param, double *get, int32_t do_step,
                         void *stream);
 int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const double *obst, int32_t n_steps, double *pred, void *stream);

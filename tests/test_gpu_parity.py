@@ -592,3 +592,26 @@ def test_max_iter_relinearisation_passes(pkg, oracle, routes, T):
     l2.run(K)
     torch.cuda.synchronize()
     assert torch.equal(l1.hist, l2.hist) and torch.equal(l1.x0, l2.x0) and torch.equal(e1.n_iter, e2.n_iter)
+
+
+def test_scripted_roundabout_and_arterial_obstacles(pkg, routes):
+    """MovingObstacleRoundabout (heading rewritten by its steering property) and MovingObstacleArterial on the device against
+    the reference classes' own get()/step() sequences."""
+    g = load_golden("obstacles_scripted.npz")
+    eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
+    specs = [dict(kind="roundabout", direction=int(d), turning=bool(t), speed=float(s), offset=None if o < 0 else float(o))
+             for d, t, s, o in zip(g["r_direction"], g["r_turning"], g["r_speed"], g["r_offset"])]
+    specs += [dict(kind="arterial", x_init=float(x), y_init=float(y), speed=float(s), initial_speed=float(v0),
+                   offset=None if o < 0 else float(o))
+              for x, y, s, v0, o in zip(g["a_x"], g["a_y"], g["a_speed"], g["a_v0"], g["a_offset"])]
+    ob = pkg.ScriptedObstacles(eng, specs)
+    nr = len(g["r_direction"])
+    steered = rewritten = False
+    for k in range(g["r_get"].shape[0]):
+        cur = ob.get(step=False).cpu().numpy().copy()     # the scenario calls get() and, later in the tick, step()
+        got = ob.get(step=True).cpu().numpy()
+        np.testing.assert_allclose(cur[:nr], g["r_get"][k], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(cur[nr:], g["a_get"][k], rtol=0, atol=1e-10)
+        steered |= bool((cur[:nr, 5] != 0).any())
+        rewritten |= bool(np.any(np.abs(np.abs(cur[:nr, 3]) - np.pi) < 1e-12) and k > 5)
+    assert steered and rewritten
