@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Diagnostic soak: the HIP step against the CPU oracle over many seeded ego batches (more than the test suite can
+afford), every horizon that has a register kernel plus one that takes the LDS kernel.  Prints, per horizon, the worst
+|du|, how many active sets / statuses / target indices differ and how often the iteration count is identical.
+Uses oracle/ as the checker only (tools/ is diagnostics, like tests/).
+
+    python tools/soak_parity.py [seeds=8] [B=512]
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+pkg = importlib.import_module("av-simulation-at-intersections_amd")
+import oracle_py as oracle  # noqa: E402
+
+NSEED = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+S = pkg.synth
+routes = S.make_route_table()
+for r in routes:
+    S.smooth_yaw_inplace(r[:, 2])
+cx, cy, cyaw, off = S.pack_paths(routes)
+bad = 0
+for T in (13, 20, 30, 40, 25):
+    worst = 0.0
+    n_mask = n_stat = n_tind = n_ego = 0
+    same_it = 0
+    t0 = time.time()
+    for seed in range(100, 100 + NSEED):
+        batch = S.make_ego_batch(routes, B, T, seed=seed, truncate=(seed % 2 == 0), near_end_frac=0.15)
+        eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device="cuda:0", smooth=False)
+        eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+        eng.solve(torch.from_numpy(batch.x0).cuda())
+        torch.cuda.synchronize()
+        p = oracle.make_params(T=T)
+        ref = oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off,
+                                    batch.target_ind, batch.oa, batch.od)
+        st = eng.status.cpu().numpy()
+        ok = (st == 0) & (ref["status"] == 0)
+        n_stat += int((st != ref["status"]).sum())
+        n_tind += int((eng.target_ind.cpu().numpy() != ref["target_ind"]).sum())
+        mk = eng.active_mask.cpu().numpy().view(np.uint32)
+        n_mask += int((mk != ref["active_mask"]).any(axis=1).sum())
+        du = max(np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max(), np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max())
+        worst = max(worst, float(du))
+        same_it += int((eng.n_iter.cpu().numpy() == ref["n_iter"]).sum())
+        n_ego += B
+        del eng
+    print(f"T={T:2d}: {n_ego} egos, max|du| {worst:.2e}, status diffs {n_stat}, target_ind diffs {n_tind}, "
+          f"active-set diffs {n_mask}, n_iter identical {100.0 * same_it / n_ego:.2f} %  ({time.time() - t0:.0f} s)", flush=True)
+    bad += n_stat + n_tind + n_mask + (worst > 1e-4)
+print("SOAK", "CLEAN" if bad == 0 else f"FOUND {bad} DIFFERENCES")
+sys.exit(0 if bad == 0 else 1)
