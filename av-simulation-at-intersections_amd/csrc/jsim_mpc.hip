@@ -983,7 +983,11 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K)
 {
     if (T == 13) hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
     else if (T == 20) hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
+#ifdef JSIM_T30_TWO_WAVE
     else if (T == JSIM_REG2_T_A) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_A>, dim3(B), dim3(128), 0, s, P, K);
+#else
+    else if (T == 30) hipLaunchKernelGGL(mpc_step_reg_kernel<30>, dim3(B), dim3(64), 0, s, P, K);
+#endif
 #if JSIM_REG2_T_B != JSIM_REG2_T_A
     else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_B>, dim3(B), dim3(128), 0, s, P, K);
 #endif
