@@ -201,12 +201,12 @@ def main():
                        "respawns": int(loop.n_respawn.item())},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": (f"mpc_step_reg_kernel<{T}>" if T in (13, 20) else
-                                    f"mpc_step_reg2_kernel<{T}>" if T in (30, 40) else "mpc_step_kernel"), "kernel_ms": kern_ms,
+                         "kernel": (f"mpc_step_reg_kernel<{T}>" if T in (13, 20, 30) else
+                                    f"mpc_step_reg2_kernel<{T}>" if T == 40 else "mpc_step_kernel"), "kernel_ms": kern_ms,
                          "ticks_per_launch": ticks_per_launch,
                          "algorithmic_flops_per_launch": flops,
                          "note": ("fp64 vector/matrix peak; latency-bound: " +
-                                  (f"{1 if T <= 21 else 2} wave(s) per ego, {B} egos on 256 CUs (1024 SIMDs)"))},
+                                  (f"{2 if T == 40 else 1} wave(s) per ego, {B} egos on 256 CUs (1024 SIMDs)"))},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes},
         }

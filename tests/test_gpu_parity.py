@@ -524,6 +524,39 @@ def test_two_wave_kernel_large_working_sets(pkg, oracle, routes, T):
     assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32)[ok], ref["active_mask"][ok])
 
 
+@pytest.mark.parametrize("T", (20, 30, 40))
+def test_speed_rows_in_the_working_set(pkg, oracle, routes, T):
+    """Egos that start at (or within 0.3 m/s of) a low speed limit with an accelerating warm start: the v_t <= speed rows
+    fill the working set.  T = 30 is the case that matters: its one-wave kernel keeps NO speed rows -- it evaluates them
+    as prefix sums over the acceleration lanes and forms a row in LDS only when it enters (mpc_step_reg.inc, VS)."""
+    B = 96
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=11)
+    rng = np.random.default_rng(5)
+    batch.speed[:] = rng.uniform(1.0, 8.0, B)
+    batch.x0[:, 2] = batch.speed - rng.uniform(0.0, 0.3, B)
+    batch.x0[::7, 2] = batch.speed[::7]              # exactly at the limit
+    batch.oa[:] = rng.uniform(0.5, 2.0, (B, T))
+    eng = _engine(pkg, routes, batch, T)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+    torch.cuda.synchronize()
+    _, ref = _oracle_batch(oracle, pkg, routes, batch, T)
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st, ref["status"])
+    ok = st == 0
+    assert ok.sum() >= B - 4
+    mk = eng.active_mask.cpu().numpy().view(np.uint32)
+    assert np.array_equal(mk, ref["active_mask"])
+    vu = np.zeros(B, dtype=int)
+    for cid in range(2 * T - 2, 3 * T - 1):          # canonical ids of the v_t <= speed rows
+        vu += (mk[:, cid >> 5] >> (cid & 31)) & 1
+    print(f"T={T}: active speed rows per ego: mean {vu[ok].mean():.1f}, max {vu.max()}")
+    assert (vu[ok] >= 3).mean() > 0.5 and vu.max() >= T // 3, (vu.mean(), vu.max())
+    err = max(np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max(), np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max())
+    assert err <= 1e-7, err
+    np.testing.assert_allclose(eng.ov.cpu().numpy()[ok], ref["ov"][ok], rtol=0, atol=1e-6)
+    assert (eng.n_iter.cpu().numpy() == ref["n_iter"]).mean() >= 0.9
+
+
 @pytest.mark.parametrize("T,B", ((30, 2048), (40, 1024)))
 def test_two_wave_kernel_at_scale_and_deterministic(pkg, oracle, routes, T, B):
     """Two workgroups per CU, many rounds: every ego against the oracle (not just a KKT property), and two runs of the same
@@ -552,7 +585,7 @@ def test_two_wave_kernel_at_scale_and_deterministic(pkg, oracle, routes, T, B):
     assert same.mean() >= 0.9
 
 
-@pytest.mark.parametrize("T", (13, 20, 30, 25))
+@pytest.mark.parametrize("T", (13, 20, 30, 40, 25))
 def test_max_iter_relinearisation_passes(pkg, oracle, routes, T):
     """MAX_ITER > 1 (main/lib/mpc.py:231-236): every pass re-selects the reference window with the previous pass's
     predicted speeds, rolls out the previous solution and solves again.  Three passes against the oracle's three passes;
