@@ -72,7 +72,8 @@ for t in tags[1:]:
     if st:
         shutil.copy(st[0], os.path.join(P, f"r01_{t}_kernel_stats.csv"))
     b = p["bench_line_under_rocprof"]
-    txt += "\n" + para(p, f"{b['config']['egos_per_gpu']} egos, T = {b['config']['horizon']} (two wavefronts per ego)")
+    how = "two wavefronts per ego" if b['config']['horizon'] > 31 else "one wavefront per ego, virtual speed rows, 4 egos per CU"
+    txt += "\n" + para(p, f"{b['config']['egos_per_gpu']} egos, T = {b['config']['horizon']} ({how})")
 txt += """
 History of the default bench within round 1 (bench.py, 1 GPU, 256 egos, T = 20):
   v1 LDS-resident kernel, one launch per tick                      0.37 M steps/s   (0.67 ms per single-tick launch)   r01_v1_lds_*
@@ -84,7 +85,9 @@ History of the default bench within round 1 (bench.py, 1 GPU, 256 egos, T = 20):
   + arithmetic pinned where written (no AGPR round trips)          2.60 M           (15k VALU wave-instr per step)
   + leaner MFMA operand generation, column-oriented factorisation
     with look-ahead, pipelined forward substitution                2.78 M           (13k VALU wave-instr per step)
-Horizons 30 / 40 (4096 egos): LDS-resident kernel 0.84 / 0.18 M steps/s -> two-wave register kernel 2.9 / 1.3 M.
+  + two-wave kernel's constants read as LDS / global (not FLAT), single-pass publish   2.9 M   (12.8k VALU wave-instr per step)
+Horizons 30 / 40 (4096 egos): LDS-resident kernel 0.84 / 0.18 M steps/s -> two-wave register kernel 3.2 / 1.4 M
+-> T = 30 in ONE wave per ego (speed rows virtual, 40 KB of LDS: four egos per CU) 5.3 M.
 Other shapes, same build (r01_other_configs.txt: egos, T, steps/s, ms per tick, mean iterations, fp64 roofline fraction).
 Files: r01_bench_fused_kernel_stats.csv (rocprofv3 --stats), r01_bench_fused_pmc_summary.json (per-launch counter means; bench.py
 reads FETCH_SIZE / WRITE_SIZE from it for `roofline.traffic`), r01_bench_fused_under_rocprof.json (bench line of the traced run),
