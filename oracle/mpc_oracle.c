@@ -197,6 +197,9 @@ void orc_linear_model_matrix(double v, double phi, double delta, double dt, doub
     C[3] = -dt * v * delta / (L * (cd * cd));
 }
 
+int orc_nx(const orc_params *p) { return p->nx == 5 ? 5 : 4; }
+int orc_nvar(const orc_params *p) { return 2 * p->T + (p->nx == 5 ? 1 : 0); }
+
 /* main/lib/mpc.py:132-138 */
 static void xy_cost_mtx(double angle, double P[4])
 {
@@ -215,35 +218,50 @@ static void xy_cost_mtx(double angle, double P[4])
  *   => H = 2 (S'QS + Rbar + D'Rd D),  g = 2 S'Q (fresp - xref); multipliers of G u <= h are then the
  *   reference problem's own.
  * ---------------------------------------------------------------------------------------------- */
+/* The acceleration-state variant (main/lib/mpc_jerk.py, p->nx == 5): state [x, y, v, yaw, acc] with
+ *   A[4][4] = 1, A[2][4] = dt, B[4][0] = dt                                     (mpc_jerk.py:67,73,78)
+ * on top of the stock model, `x[:4, 0] == x0` only (:193) -- acc_0 is a FREE variable, carried here as the last
+ * decision variable (index 2T, n = 2T + 1) -- and the cost term (x[4,t+1] - x[4,t])^2 for t < T-1 (:190).
+ * xref / xbar / Qf keep their four stock rows: the fifth ones are zero in the reference (xref = zeros, xbar = 0 * xref,
+ * Qf[4][4] = 0, and :174 weighs x[2:4] only). */
 int orc_build_qp(const orc_params *p, const double *xref, const double *xbar, const double x0[4],
                  const uint8_t *reaches_end, double speed, double *H, double *g, double *G, double *h,
                  uint8_t *skip, double *fresp, double *Sens)
 {
-    const int T = p->T, n = 2 * T, m = 8 * T, W = T + 1;
+    const int NX = orc_nx(p), T = p->T, n = orc_nvar(p), m = 8 * T, W = T + 1;
     memset(H, 0, sizeof(double) * n * n);
     memset(g, 0, sizeof(double) * n);
     memset(G, 0, sizeof(double) * m * n);
     memset(h, 0, sizeof(double) * m);
     memset(skip, 0, m);
-    memset(Sens, 0, sizeof(double) * 4 * W * n);
+    memset(Sens, 0, sizeof(double) * NX * W * n);
+    memset(fresp, 0, sizeof(double) * NX * W);
 
     for (int r = 0; r < 4; ++r) fresp[r * W] = x0[r];
-    /* Sens stored as [t][r][c] -> index ((t*4 + r) * n + c) */
+    if (NX == 5) Sens[(0 * NX + 4) * n + 2 * T] = 1.0; /* x[4,0] = acc_0 */
+    /* Sens stored as [t][r][c] -> index ((t*NX + r) * n + c) */
     for (int t = 0; t < T; ++t) {
-        double A[16], Bm[8], C[4];
+        double A4[16], B4[8], C4[4], A[25], Bm[10], C[5];
         /* dref[0,t] == 0 always (mpc.py:96) */
-        orc_linear_model_matrix(xbar[2 * W + t], xbar[3 * W + t], 0.0, p->dt, p->L, A, Bm, C);
+        orc_linear_model_matrix(xbar[2 * W + t], xbar[3 * W + t], 0.0, p->dt, p->L, A4, B4, C4);
+        memset(A, 0, sizeof(A)); memset(Bm, 0, sizeof(Bm)); memset(C, 0, sizeof(C));
         for (int r = 0; r < 4; ++r) {
+            for (int k = 0; k < 4; ++k) A[r * NX + k] = A4[r * 4 + k];
+            Bm[r * 2 + 0] = B4[r * 2 + 0]; Bm[r * 2 + 1] = B4[r * 2 + 1];
+            C[r] = C4[r];
+        }
+        if (NX == 5) { A[4 * NX + 4] = 1.0; A[2 * NX + 4] = p->dt; Bm[4 * 2 + 0] = p->dt; }
+        for (int r = 0; r < NX; ++r) {
             double acc = C[r];
-            for (int k = 0; k < 4; ++k) acc += A[r * 4 + k] * fresp[k * W + t];
+            for (int k = 0; k < NX; ++k) acc += A[r * NX + k] * fresp[k * W + t];
             fresp[r * W + t + 1] = acc;
             for (int c = 0; c < n; ++c) {
                 double s = 0.0;
-                for (int k = 0; k < 4; ++k) s += A[r * 4 + k] * Sens[((t * 4) + k) * n + c];
-                Sens[(((t + 1) * 4) + r) * n + c] = s;
+                for (int k = 0; k < NX; ++k) s += A[r * NX + k] * Sens[((t * NX) + k) * n + c];
+                Sens[(((t + 1) * NX) + r) * n + c] = s;
             }
-            Sens[(((t + 1) * 4) + r) * n + 2 * t + 0] += Bm[r * 2 + 0];
-            Sens[(((t + 1) * 4) + r) * n + 2 * t + 1] += Bm[r * 2 + 1];
+            Sens[(((t + 1) * NX) + r) * n + 2 * t + 0] += Bm[r * 2 + 0];
+            Sens[(((t + 1) * NX) + r) * n + 2 * t + 1] += Bm[r * 2 + 1];
         }
     }
 
@@ -266,7 +284,7 @@ int orc_build_qp(const orc_params *p, const double *xref, const double *xbar, co
         } else {
             for (int r = 0; r < 4; ++r) Q[r * 4 + r] = p->Qf[r] * (double)T; /* Qf * T, mpc.py:28 */
         }
-        const double *St = &Sens[(t * 4) * n];
+        const double *St = &Sens[(t * NX) * n];
         double e[4], Qe[4];
         for (int r = 0; r < 4; ++r) e[r] = fresp[r * W + t] - xref[r * W + t];
         for (int r = 0; r < 4; ++r) {
@@ -284,6 +302,18 @@ int orc_build_qp(const orc_params *p, const double *xref, const double *xbar, co
                 double s = 0.0;
                 for (int r = 0; r < 4; ++r) s += St[r * n + j] * QSi[r];
                 H[j * n + i] += 2.0 * s;
+            }
+        }
+    }
+    /* mpc_jerk.py:190  jerk_penalty_weight * (x[4,t+1] - x[4,t])^2,  t < T-1 */
+    if (NX == 5) {
+        for (int t = 0; t + 1 < T; ++t) {
+            const double *Sa = &Sens[(t * NX + 4) * n], *Sb = &Sens[((t + 1) * NX + 4) * n];
+            const double df = fresp[4 * W + t + 1] - fresp[4 * W + t];
+            for (int i = 0; i < n; ++i) {
+                const double di = Sb[i] - Sa[i];
+                g[i] += 2.0 * p->jerk_weight * df * di;
+                for (int j = 0; j < n; ++j) H[i * n + j] += 2.0 * p->jerk_weight * di * (Sb[j] - Sa[j]);
             }
         }
     }
@@ -324,7 +354,7 @@ int orc_build_qp(const orc_params *p, const double *xref, const double *xbar, co
     }
     for (int t = 0; t <= T; ++t) { /* VU (:190), VL (:191) */
         int ru = 2 * T - 2 + t, rl = 3 * T - 1 + t;
-        const double *Sv = &Sens[(t * 4 + 2) * n];
+        const double *Sv = &Sens[(t * NX + 2) * n];
         for (int c = 0; c < n; ++c) {
             G[ru * n + c] = Sv[c];
             G[rl * n + c] = -Sv[c];
@@ -619,7 +649,7 @@ int orc_mpc_step_cv(const orc_params *p, double sx, double sy, double syaw, doub
                     const double *cy, const double *cyaw, const double *cv, int64_t cv_cut, int64_t ncourse,
                     int64_t target_ind, double speed, const double *oa_in, const double *od_in, orc_step_out *out)
 {
-    const int T = p->T, n = 2 * T, m = 8 * T, W = T + 1;
+    const int NX = orc_nx(p), T = p->T, n = orc_nvar(p), m = 8 * T, W = T + 1;
     double x0[4] = {sx, sy, sv, syaw}; /* mpc.py:291 */
     double *oa = (double *)calloc(T, sizeof(double));
     double *od = (double *)calloc(T, sizeof(double));
@@ -632,8 +662,8 @@ int orc_mpc_step_cv(const orc_params *p, double sx, double sy, double syaw, doub
     double *G = (double *)malloc(sizeof(double) * m * n);
     double *h = (double *)malloc(sizeof(double) * m);
     uint8_t *skip = (uint8_t *)malloc(m);
-    double *fresp = (double *)malloc(sizeof(double) * 4 * W);
-    double *Sens = (double *)malloc(sizeof(double) * 4 * W * n);
+    double *fresp = (double *)malloc(sizeof(double) * NX * W);
+    double *Sens = (double *)malloc(sizeof(double) * NX * W * n);
     double *u = (double *)malloc(sizeof(double) * n);
     double *lam = (double *)malloc(sizeof(double) * m);
     double *ovprev = (double *)malloc(sizeof(double) * W);
@@ -667,7 +697,7 @@ int orc_mpc_step_cv(const orc_params *p, double sx, double sy, double syaw, doub
             double zt[4];
             for (int r = 0; r < 4; ++r) {
                 double s = fresp[r * W + t];
-                const double *Sr = &Sens[(t * 4 + r) * n];
+                const double *Sr = &Sens[(t * NX + r) * n];
                 for (int c = 0; c < n; ++c) s += Sr[c] * u[c];
                 zt[r] = s;
             }

@@ -66,7 +66,13 @@ typedef struct orc_params {
     double min_ref_speed; /* 10/3.6, mpc.py:99 */
     double goal_dis;      /* GOAL_DIS */
     double stop_speed;    /* STOP_SPEED */
+    int32_t nx;           /* 4: main/lib/mpc.py; 5: main/lib/mpc_jerk.py (acceleration state, free acc_0, n = 2T + 1 variables) */
+    int32_t reserved_;
+    double jerk_weight;   /* jerk_penalty_weight (mpc_jerk.py:31), nx == 5 only */
 } orc_params;
+
+int orc_nx(const orc_params *p);   /* 4 or 5 */
+int orc_nvar(const orc_params *p); /* 2T, or 2T + 1 with the acceleration state */
 
 /* status codes shared with the product C-ABI (include/jsim_mpc.h) */
 enum {

@@ -40,6 +40,7 @@ class OrcParams(C.Structure):
         ("max_dsteer", C.c_double), ("max_accel", C.c_double), ("max_decel", C.c_double),
         ("max_steer", C.c_double), ("max_speed", C.c_double), ("min_speed", C.c_double),
         ("min_ref_speed", C.c_double), ("goal_dis", C.c_double), ("stop_speed", C.c_double),
+        ("nx", C.c_int32), ("reserved_", C.c_int32), ("jerk_weight", C.c_double),
     ]
 
 
@@ -77,7 +78,14 @@ def make_params(T: int = 13, dt: float = 0.2, dl: float = 0.083, L: float = 2.86
     p.min_ref_speed = 10 / 3.6                      # mpc.py:99
     p.goal_dis = float(cfg["GOAL_DIS"])
     p.stop_speed = float(cfg["STOP_SPEED"])
+    p.nx = int(cfg.get("NX", 4))                    # 5: main/lib/mpc_jerk.py
+    p.jerk_weight = float(cfg.get("JERK_WEIGHT", 1.0))  # mpc_jerk.py:31
     return p
+
+
+def nvar(p) -> int:
+    """Decision variables of the condensed QP: 2T, plus the free acc_0 of the acceleration-state variant."""
+    return 2 * p.T + (1 if p.nx == 5 else 0)
 
 
 def build(force: bool = False) -> str:
@@ -190,10 +198,10 @@ def linear_model_matrix(v, phi, delta, dt, L):
 
 
 def build_qp(p, xref, xbar, x0, reaches_end, speed):
-    T = p.T; n = 2 * T; m = 8 * T
+    T = p.T; n = nvar(p); m = 8 * T; NX = 5 if p.nx == 5 else 4
     H = np.zeros((n, n)); g = np.zeros(n); G = np.zeros((m, n)); h = np.zeros(m)
     skip = np.zeros(m, dtype=np.uint8)
-    fresp = np.zeros((4, T + 1)); Sens = np.zeros((4 * (T + 1), n))
+    fresp = np.zeros((NX, T + 1)); Sens = np.zeros((NX * (T + 1), n))
     st = lib().orc_build_qp(C.byref(p), _c(xref), _c(xbar), _c(x0), _c(reaches_end, np.uint8),
                             float(speed), H, g, G, h, skip, fresp, Sens)
     return int(st), H, g, G, h, skip, fresp, Sens
@@ -215,7 +223,7 @@ def active_indices_from_mask(mask_row, m):
 def mpc_step(p, state_xyyawv, cx, cy, cyaw, target_ind, speed, oa=None, od=None, want_qp=False, cv=None, cv_cut=-1):
     """One reference MPC.step for one ego.  state = (x, y, yaw, v) like lib.simulation.State.
     cv / cv_cut: the mpc_with_speed variant's per-point speed reference, zeroed from index cv_cut on."""
-    T = p.T; n = 2 * T; m = 8 * T
+    T = p.T; n = nvar(p); m = 8 * T
     res = {
         "oa": np.zeros(T), "od": np.zeros(T), "ox": np.zeros(T + 1), "oy": np.zeros(T + 1),
         "ov": np.zeros(T + 1), "oyaw": np.zeros(T + 1), "xref": np.zeros((4, T + 1)),

@@ -198,3 +198,53 @@ def test_generic_solver_detects_infeasible():
     G = np.array([[1.0, 0.0], [-1.0, 0.0]]); h = np.array([-1.0, -1.0])   # x <= -1 and x >= 1
     st_, u, lam, it = oracle.solve_qp(H, g, G, h)
     assert st_ == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# the acceleration-state variant (main/lib/mpc_jerk.py): 2T + 1 decision variables
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T", (13, 20))
+def test_jerk_variant_condensed_qp_equals_its_sparse_form_and_solves(oracle, pkg, routes, T):
+    """lib/mpc_jerk.py is dead code in the reference (only commented-out imports), so nothing but its source pins it:
+    the oracle's condensed (H, g, G, h) with the free acc_0 as variable 2T against an independent numpy restatement of
+    the variant's sparse cvxpy problem, then the exact solve by KKT residuals and an active-set re-solve."""
+    cfg = dict(QS.JERK_CONFIG)
+    p = oracle.make_params(T=T, config=cfg)
+    assert p.nx == 5 and oracle.nvar(p) == 2 * T + 1
+    batch = _ego_cases(pkg, routes, T, n=10, seed=31)
+    vmax = 30 / 3.6                                     # Simulation.MAX_SPEED (mpc_jerk.py:194), not the ego's speed
+    n_act = 0
+    for b in range(10):
+        r, xref, xbar, rend = _stages(oracle, p, routes, batch, b)
+        st_, H, g, G, h, skip, fresp, Sens = oracle.build_qp(p, xref, xbar, batch.x0[b], rend, vmax)
+        assert st_ == 0
+        P, q, c0, Aeq, beq, Gin, hin = QS.build_sparse_jerk(cfg, T, p.dt, p.L, xref, xbar, batch.x0[b], rend, vmax)
+        H2, g2, G2, h2, Phi, phi = QS.condense_jerk(P, q, Aeq, beq, Gin, hin, T)
+        sc = np.abs(H2).max()
+        assert H.shape == (2 * T + 1, 2 * T + 1)
+        assert np.abs(H - H2).max() <= 1e-10 * sc
+        assert np.abs(g - g2).max() <= 1e-9 * max(1.0, np.abs(g2).max())
+        assert np.abs(G - G2).max() <= 1e-12
+        assert np.abs(h - h2).max() <= 1e-11
+        np.testing.assert_allclose(Sens, Phi, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(fresp.T.reshape(-1), phi, rtol=0, atol=1e-10)
+        assert np.linalg.eigvalsh(H).min() > 0.0        # acc_0 has no cost of its own: curvature comes through v -> x, y
+        st2, u, lam, it = oracle.solve_qp(H, g, G, h, skip)
+        assert st2 == 0
+        thr = 1e-9 * max(1.0, np.abs(g).max())
+        active = [i for i in range(8 * T) if lam[i] > thr]
+        n_act += len(active)
+        _verify_solution(H, g, G, h, skip, u, lam, active)
+        res = oracle.mpc_step(p, (batch.x0[b][0], batch.x0[b][1], batch.x0[b][3], batch.x0[b][2]),
+                              r[:, 0], r[:, 1], r[:, 2], int(batch.target_ind[b]), vmax,
+                              oa=batch.oa[b], od=batch.od[b], want_qp=True)
+        assert res["status"] == 0 and res["active"] == active
+        np.testing.assert_array_equal(res["oa"], u[0:2 * T:2])     # oa = u[0, :], the input of the acceleration state
+        np.testing.assert_array_equal(res["od"], u[1:2 * T:2])
+        z = fresp + (Sens @ u).reshape(T + 1, 5).T
+        np.testing.assert_allclose(np.stack([res["ox"], res["oy"], res["ov"], res["oyaw"]]), z[:4], atol=1e-12)
+        # v_{t+1} = v_t + dt * (acc_t + u0_t),  acc_{t+1} = acc_t + dt * u0_t  (mpc_jerk.py:67-78)
+        acc = np.concatenate([[u[2 * T]], u[2 * T] + p.dt * np.cumsum(u[0:2 * T:2])])
+        np.testing.assert_allclose(z[4], acc, atol=1e-12)
+        np.testing.assert_allclose(np.diff(z[2]), p.dt * (acc[:-1] + u[0:2 * T:2]), atol=1e-12)
+    assert n_act > 0
