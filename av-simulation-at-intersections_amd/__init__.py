@@ -16,3 +16,4 @@ from . import mpc  # noqa: F401
 from .mpc import MPC, MAX_ACCEL, MAX_DECEL, MPCSolutionNotFoundException  # noqa: F401
 from . import mpc_with_speed  # noqa: F401
 from . import mpc_sensitivity  # noqa: F401
+from . import mpc_jerk  # noqa: F401

@@ -12,7 +12,7 @@ from .config import MPCConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjsim_mpc.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class JsimCfg(C.Structure):
@@ -25,6 +25,7 @@ class JsimCfg(C.Structure):
         ("max_dsteer", C.c_double), ("max_accel", C.c_double), ("max_decel", C.c_double),
         ("max_steer", C.c_double), ("max_speed", C.c_double), ("min_speed", C.c_double),
         ("min_ref_speed", C.c_double), ("goal_dis", C.c_double), ("stop_speed", C.c_double),
+        ("nx", C.c_int32), ("reserved_", C.c_int32), ("jerk_weight", C.c_double),
     ]
 
 
@@ -118,6 +119,8 @@ def make_cfg(config: MPCConfig, T: int, dt: float, dl: float, L: float) -> JsimC
     c.min_ref_speed = float(config.MIN_REF_SPEED)
     c.goal_dis = float(config.GOAL_DIS)
     c.stop_speed = float(config.STOP_SPEED)
+    c.nx = int(config.NX)
+    c.jerk_weight = float(config.JERK_WEIGHT)
     return c
 
 

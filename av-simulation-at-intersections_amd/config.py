@@ -43,6 +43,8 @@ class MPCConfig:
     # literals in main/lib/mpc.py
     R_END: List[float] = field(default_factory=lambda: [10.0, 10.0])  # :181
     MIN_REF_SPEED: float = 10 / 3.6                                    # :99
+    # NX = 5 only (main/lib/mpc_jerk.py:31,190): weight of (x[4,t+1] - x[4,t])^2
+    JERK_WEIGHT: float = 1.0
 
     @classmethod
     def from_json(cls, path: Optional[str] = None) -> "MPCConfig":
@@ -50,8 +52,8 @@ class MPCConfig:
             raw = json.load(f)
         known = {k: raw[k] for k in raw if k in cls.__dataclass_fields__}
         cfg = cls(**known)
-        if cfg.NX != 4 or cfg.NU != 2:
-            raise ValueError("only NX=4, NU=2 (the kinematic bicycle of main/lib/mpc.py) is supported")
+        if cfg.NX not in (4, 5) or cfg.NU != 2:
+            raise ValueError("NX must be 4 (main/lib/mpc.py) or 5 (the acceleration state of main/lib/mpc_jerk.py), NU = 2")
         return cfg
 
     @property

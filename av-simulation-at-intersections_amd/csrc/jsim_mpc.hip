@@ -69,6 +69,7 @@ struct KP {
     double dt, dl, L, w_perp, w_para;
     double R0, R1, Rd0, Rd1, Qv, Qyaw, Qf0, Qf1, Qf2, Qf3, Re0, Re1; // Qf* already multiplied by T
     double dmax, amax, amin, smax, vmax_plant, vmin, vref_min;
+    double jerkw; // acceleration-state variant (main/lib/mpc_jerk.py, n = 2T + 1): jerk_penalty_weight
     const double2 *pxy;
     const double *pyaw;
     const double *pcv;   // per-point speed reference of the mpc_with_speed variant, or NULL (xref[2] = 0, mpc.py:107)
@@ -185,15 +186,24 @@ __device__ __forceinline__ double wexscan(double v, int lane)
 enum { TQ_PA = 0, TQ_PB, TQ_PAP, TQ_PBP, TQ_KT, TQ_QXX, TQ_QXY, TQ_QYY, TQ_QV, TQ_QYAW, TQ_QEX, TQ_QEY,
        TQ_QEV, TQ_QEYAW, TQ_REND, TQ_ONE, TQ_ZERO /* constant rows for the register kernels' operand tables */, TQ_COUNT };
 
-__host__ __device__ static inline size_t jsim_lds_doubles(int T)
+// n = 2T decision variables (2T + 1 with the free acc_0 of the acceleration-state variant); ld = row stride of J / R (odd);
+// vectors are sized nv = n rounded up to even so that each stays 16-byte aligned
+__host__ __device__ static inline int jsim_nvar(int T, int jerk) { return 2 * T + (jerk ? 1 : 0); }
+__host__ __device__ static inline int jsim_ld(int n) { return (n + 1) | 1; }
+__host__ __device__ static inline size_t jsim_lds_doubles(int T, int jerk)
 {
-    const size_t n = 2 * (size_t)T, ld = n + 1, tp = (size_t)T + 2;
-    //      Jm       Rm       dvec uvec   lamv gsv    rdg ldg  actv(int)  mask    tq
-    return n * ld + n * ld + n + (n + 4) + n + 2 * n + n + n + (n + 1) / 2 + 1 + ((8 * (size_t)T + 31) / 32 + 1) / 2 + 1 +
+    const size_t n = (size_t)jsim_nvar(T, jerk), ld = (size_t)jsim_ld((int)n), nv = (n + 1) & ~(size_t)1, tp = (size_t)T + 2;
+    //      Jm + Rm (even)           dvec uvec      lamv gsv     rdg  ldg  actv(int)   mask                                   tq
+    return ((2 * n * ld + 1) & ~(size_t)1) + nv + (nv + 4) + nv + 2 * nv + nv + nv + nv / 2 + 2 + ((8 * (size_t)T + 31) / 32 + 1) / 2 + 1 +
            TQ_COUNT * tp;
 }
 
-template <int RPL>
+// JERK: the acceleration-state variant of main/lib/mpc_jerk.py.  Decision vector z = [u0_0, delta_0, .., u0_{T-1}, delta_{T-1}, acc_0]:
+// the state [x, y, v, yaw] responds to the EFFECTIVE accelerations  a~_t = acc_t + u0_t = acc_0 + u0_t + dt * sum_{r<t} u0_r
+// (v_{t+1} = v_t + dt acc_t + dt u0_t, acc_{t+1} = acc_t + dt u0_t; :67-78) exactly as the stock model responds to a_t, so the
+// state-cost Hessian / gradient are the stock ones in (a~, delta) coordinates, carried to z by  a~ = E z  (suffix sums down
+// the a-rows and a-columns); the speed rows become  dt * sum_{s<t} A_s  with  A_s = J[acc_0] + J[2s] + dt * sum_{r<s} J[2r].
+template <int RPL, bool JERK>
 __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 {
     KP P = Pin;
@@ -205,19 +215,21 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
     if (P.pass > 0 && P.status[ego] != JSIM_OK) return; // failed in an earlier pass of this step: the failure stands
     const int it_base = (P.pass > 0 && P.n_iter) ? P.n_iter[ego] : 0;
     const int T = P.T, n = P.n, ld = P.ld, tp = T + 2;
+    const int nh = 2 * T;             // inputs (u0 / a, delta) x T; n = nh + 1 with the free acc_0 (JERK)
+    const int nv = (n + 1) & ~1;
     const int MW = (8 * T + 31) >> 5;
 
     double *Jm = lds;
     double *Rm = Jm + (size_t)n * ld;
-    double *dvec = Rm + (size_t)n * ld;
-    double *uvec = dvec + n;          // n + 4
-    double *lamv = uvec + n + 4;      // n
-    double *gsv = lamv + n;           // 2n  Givens (c, s)
-    double *rdg = gsv + 2 * n;        // n   1 / R[k][k]
-    double *ldg = rdg + n;            // n   1 / L[k][k]
-    int *actv = (int *)(ldg + n);     // n ints
-    unsigned *maskw = (unsigned *)(ldg + n + (n + 1) / 2 + 1);
-    double *tq = ldg + n + (n + 1) / 2 + 1 + (MW + 1) / 2 + 1;
+    double *dvec = lds + (((size_t)2 * n * ld + 1) & ~(size_t)1);
+    double *uvec = dvec + nv;         // nv + 4
+    double *lamv = uvec + nv + 4;     // nv
+    double *gsv = lamv + nv;          // 2nv  Givens (c, s)
+    double *rdg = gsv + 2 * nv;       // nv   1 / R[k][k]
+    double *ldg = rdg + nv;           // nv   1 / L[k][k]
+    int *actv = (int *)(ldg + nv);    // n ints
+    unsigned *maskw = (unsigned *)(ldg + nv + nv / 2 + 1);
+    double *tq = ldg + nv + nv / 2 + 2 + (MW + 1) / 2 + 1;
 
     // ------------------------------------------------------------------ inputs (wave-uniform)
     const int pid = P.path_id[ego];
@@ -418,11 +430,11 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
     // v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
     // D[row = (lane>>4) + 4*reg][col = lane&15].  k = state component of time step t; tile columns = 8 time steps.
     {
-        const int ntile = (n + 15) >> 4;
+        const int ntile = (nh + 15) >> 4;
         const int kk = lane >> 4, cc = lane & 15;
         for (int ti = 0; ti < ntile; ++ti) {
             const int ca = 16 * ti + cc;
-            const bool va = ca < n;
+            const bool va = ca < nh;
             const int sa = va ? (ca >> 1) : (T - 1);
             const bool isda = ca & 1;
             const double kta = tq[TQ_KT * tp + sa];
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
             const double *ptya = isda ? &tq[TQ_PBP * tp] : &tq[TQ_PAP * tp];
             for (int tj = 0; tj <= ti; ++tj) {
                 const int cb = 16 * tj + cc;
-                const bool vb = cb < n;
+                const bool vb = cb < nh;
                 const int sb = vb ? (cb >> 1) : (T - 1);
                 const bool isdb = cb & 1;
                 const double ktb = tq[TQ_KT * tp + sb];
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + kk + 4 * r, col = 16 * tj + cc;
-                    if (row < n && col < n) {
+                    if (row < nh && col < nh) {
                         double hv = 2.0 * acc[r];
                         Rm[row * ld + col] = hv;
                         if (ti != tj) Rm[col * ld + row] = hv;
@@ -481,21 +493,15 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
     LDS_SYNC();
 
     STAMP(5);
-    // input cost R / R_end (mpc.py:180-183), input-difference cost Rd (mpc.py:186), and g = 2 S'Q(f - xref)
+    // g = 2 S'Q(f - xref); [JERK: state-cost terms from (a~, delta) to z coordinates;] then the input cost R / R_end
+    // (mpc.py:180-183) and the input-difference cost Rd (mpc.py:186) [and the jerk cost, mpc_jerk.py:190]
     double gmax;
     {
-        double gl = 0.0;
 #pragma unroll
         for (int rr = 0; rr < RPL; ++rr) {
             const int i = lane + 64 * rr;
-            if (i < n) {
+            if (i < nh) {
                 const int t = i >> 1, c = i & 1;
-                const double Rt = (tq[TQ_REND * tp + t] != 0.0) ? (c ? P.Re1 : P.Re0) : (c ? P.R1 : P.R0);
-                const double rdc = 2.0 * (c ? P.Rd1 : P.Rd0);
-                const int nd = (T >= 2) ? ((t == 0 || t == T - 1) ? 1 : 2) : 0;
-                Rm[i * ld + i] += 2.0 * Rt + nd * rdc;
-                if (t + 1 < T) Rm[i * ld + i + 2] -= rdc;
-                if (t >= 1) Rm[i * ld + i - 2] -= rdc;
                 // g_i
                 const bool isd = c;
                 const double ks = tq[TQ_KT * tp + t];
@@ -513,8 +519,68 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
                         acc = fma(coef * (pty[tt] - py), tq[TQ_QEY * tp + tt], acc);
                     }
                 }
-                const double gi = 2.0 * acc;
-                dvec[i] = gi;
+                dvec[i] = 2.0 * acc;
+            }
+        }
+        if (JERK) {
+            LDS_SYNC();
+            // rows: H <- E'H.  Lane j walks column j upwards: row u0_t = row a~_t + dt * (sum of the rows a~_{t'}, t' > t); the
+            // total is the acc_0 row.  (E: a~_t = acc_0 + u0_t + dt * sum_{r<t} u0_r.)
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int j = lane + 64 * rr;
+                if (j < nh) {
+                    double S = 0.0;
+                    for (int t = T - 1; t >= 0; --t) {
+                        const double old = Rm[(2 * t) * ld + j];
+                        Rm[(2 * t) * ld + j] = fma(dt, S, old);
+                        S += old;
+                    }
+                    Rm[nh * ld + j] = S;
+                }
+            }
+            // g the same way (lane t: suffix sum over the later time steps)
+            double gs = 0.0, gt = 0.0;
+            if (lane < T) {
+                for (int t = T - 1; t > lane; --t) gs += dvec[2 * t];
+                gt = gs + dvec[2 * lane]; // lane 0: the total
+            }
+            LDS_SYNC();
+            if (lane < T) dvec[2 * lane] = fma(dt, gs, dvec[2 * lane]);
+            if (lane == 0) dvec[nh] = gt;
+            // columns: H <- (E'H) E, lane i walks row i (the new acc_0 row included)
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) {
+                const int i = lane + 64 * rr;
+                if (i < n) {
+                    double S = 0.0;
+                    for (int t = T - 1; t >= 0; --t) {
+                        const double old = Rm[i * ld + 2 * t];
+                        Rm[i * ld + 2 * t] = fma(dt, S, old);
+                        S += old;
+                    }
+                    Rm[i * ld + nh] = S;
+                }
+            }
+            LDS_SYNC();
+        }
+        double gl = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+            const int i = lane + 64 * rr;
+            if (i < nh) {
+                const int t = i >> 1, c = i & 1;
+                const double Rt = (tq[TQ_REND * tp + t] != 0.0) ? (c ? P.Re1 : P.Re0) : (c ? P.R1 : P.R0);
+                const double rdc = 2.0 * (c ? P.Rd1 : P.Rd0);
+                const int nd = (T >= 2) ? ((t == 0 || t == T - 1) ? 1 : 2) : 0;
+                double dg = 2.0 * Rt + nd * rdc;
+                if (JERK && c == 0 && t + 1 < T) dg += 2.0 * P.jerkw * (dt * dt); // (x[4,t+1] - x[4,t])^2 = (dt u0_t)^2
+                Rm[i * ld + i] += dg;
+                if (t + 1 < T) Rm[i * ld + i + 2] -= rdc;
+                if (t >= 1) Rm[i * ld + i - 2] -= rdc;
+            }
+            if (i < n) {
+                const double gi = dvec[i];
                 gl = fmax(gl, fabs(gi));
                 if (P.dbg_g) P.dbg_g[(size_t)ego * n + i] = gi;
             }
@@ -637,8 +703,14 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
         for (int rr = 0; rr < RPL; ++rr) {
             const int j = lane + 64 * rr;
             if (j < n) {
-                double c = 0.0;
-                for (int ss = 0; ss < T; ++ss) { c += Jm[(2 * ss) * ld + j]; Rm[(ss + 1) * ld + j] = c; }
+                double c = 0.0, pj = 0.0;
+                const double jt = JERK ? Jm[nh * ld + j] : 0.0;
+                for (int ss = 0; ss < T; ++ss) {
+                    const double a = Jm[(2 * ss) * ld + j];
+                    c += JERK ? jt + a + dt * pj : a; // JERK: A_s = J[acc_0] + J[2s] + dt * sum_{r<s} J[2r]
+                    pj += a;
+                    Rm[(ss + 1) * ld + j] = c;
+                }
             }
         }
         LDS_SYNC();
@@ -670,7 +742,9 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
             const int t = lane;
             double a = 0.0, dl_ = 0.0, dnext = 0.0;
             if (t < T) { double2 ad = *(const double2 *)&uvec[2 * t]; a = ad.x; dl_ = ad.y; dnext = uvec[2 * t + 3]; }
-            const double vt = sv + dt * wexscan(a, lane);
+            double aeff = a; // JERK: the effective acceleration a~_t = acc_0 + u0_t + dt * sum_{r<t} u0_r
+            if (JERK) aeff = t < T ? uvec[nh] + a + dt * wexscan(a, lane) : 0.0;
+            const double vt = sv + dt * wexscan(aeff, lane);
             double best = 0.0, bviol = 0.0;
             int bid = 0x7fffffff;
 #define CONSIDER(valid, bit, viol_expr, habs, id_expr, iw)                               \
@@ -723,8 +797,13 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
                         double e = Jm[(2 * tp_ + 1) * ld + j] - Jm[(2 * tp_ + 3) * ld + j]; // -(J[d_{t+1}] - J[d_t])
                         dj = neg ? -e : e;
                     } else if (kind == 1 || kind == 2) {
-                        double s = 0.0;
-                        for (int ss = 0; ss < tp_; ++ss) s += Jm[(2 * ss) * ld + j];
+                        double s = 0.0, pj = 0.0;
+                        const double jt = JERK ? Jm[nh * ld + j] : 0.0;
+                        for (int ss = 0; ss < tp_; ++ss) {
+                            const double a = Jm[(2 * ss) * ld + j];
+                            s += JERK ? jt + a + dt * pj : a;
+                            pj += a;
+                        }
                         dj = (kind == 1) ? -dt * s : dt * s;
                     } else if (kind == 3) dj = -Jm[(2 * tp_) * ld + j];
                     else if (kind == 4) dj = Jm[(2 * tp_) * ld + j];
@@ -902,6 +981,10 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
                     violp = (neg ? -e : e) - P.dmax;
                 } else if (kind == 1 || kind == 2) {
                     double a = (lane < tp_) ? uvec[2 * lane] : 0.0;
+                    if (JERK) {
+                        const double u0 = lane < T ? uvec[2 * lane] : 0.0;
+                        a = (lane < tp_) ? uvec[nh] + u0 + dt * wexscan(u0, lane) : 0.0;
+                    }
                     double vt = sv + dt * uni(wsum(a));
                     violp = (kind == 1) ? vt - speed : P.vmin - vt;
                 } else if (kind == 3) violp = uvec[2 * tp_] - P.amax;
@@ -947,7 +1030,9 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
         double a = 0.0, dl_ = 0.0;
         if (tl) { double2 ad = *(const double2 *)&uvec[2 * lane]; a = ad.x; dl_ = ad.y; }
         // predicted states of the linearised model at u* (= the cvxpy x variable)
-        const double vt = sv + dt * wexscan(a, lane);
+        double aeff = a;
+        if (JERK) aeff = tl ? uvec[nh] + a + dt * wexscan(a, lane) : 0.0;
+        const double vt = sv + dt * wexscan(aeff, lane);
         const double yt = syaw + wexscan(kt * dl_, lane);
         const double xt = sx + wexscan(fma(al, vt, fma(be, yt, ccx)), lane);
         const double yy = sy + wexscan(fma(alp, vt, fma(bep, yt, ccy)), lane);
@@ -1185,17 +1270,21 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     if (!(cfg->dt > 0) || !(cfg->dl > 0) || !(cfg->L > 0)) return fail(nullptr, -22, "jsim_mpc_create: dt, dl, L must be positive");
     if (!(cfg->R[0] > 0) || !(cfg->R[1] > 0) || !(cfg->R_end[0] > 0) || !(cfg->R_end[1] > 0))
         return fail(nullptr, -22, "jsim_mpc_create: R / R_end must be positive (strict convexity)");
+    if (cfg->nx != 4 && cfg->nx != 5) return fail(nullptr, -22, "jsim_mpc_create: NX=%d (4: lib/mpc.py, 5: lib/mpc_jerk.py)", cfg->nx);
+    if (cfg->nx == 5 && !(cfg->jerk_weight >= 0)) return fail(nullptr, -22, "jsim_mpc_create: jerk_weight must be >= 0");
     int ndev = 0;
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(nullptr, -19, "jsim_mpc_create: no HIP device");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -22, "jsim_mpc_create: device %d of %d", device_id, ndev);
-    const size_t lds_bytes = jsim_lds_doubles(cfg->T) * sizeof(double);
+    const size_t lds_bytes = jsim_lds_doubles(cfg->T, cfg->nx == 5) * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(nullptr, -22, "jsim_mpc_create: T=%d needs %zu B of LDS (> 160 KiB)", cfg->T, lds_bytes);
     HIP_TRY(nullptr, hipSetDevice(device_id));
     // dynamic LDS above the 64 KiB default has to be granted per kernel; done once here so that the step call
     // itself is pure launches (it may be captured into a hipGraph)
-    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     jsim_ctx *c = new (std::nothrow) jsim_ctx();
     if (!c) return fail(nullptr, -12, "jsim_mpc_create: out of memory");
     memset(c, 0, sizeof(*c));
@@ -1206,7 +1295,7 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     // JSIM_FORCE_LDS_KERNEL=1 routes those through the generic LDS-resident kernel too (used by the tests to
     // cover both kernels on the same inputs)
     const char *force = getenv("JSIM_FORCE_LDS_KERNEL");
-    c->use_reg_kernel = has_reg_kernel(cfg->T) && !(force && force[0] == '1');
+    c->use_reg_kernel = cfg->nx == 4 && has_reg_kernel(cfg->T) && !(force && force[0] == '1');
     const char *mg = getenv("JSIM_DEBUG_MAX_GI");
     c->dbg_max_gi = mg ? atoi(mg) : -1;
     *out = c;
@@ -1290,7 +1379,8 @@ static void fill_kp(const jsim_ctx *ctx, int32_t B, KP &P)
 {
     const jsim_cfg &c = ctx->cfg;
     memset(&P, 0, sizeof(P));
-    P.T = c.T; P.n = 2 * c.T; P.ld = 2 * c.T + 1; P.B = B;
+    P.T = c.T; P.n = jsim_nvar(c.T, c.nx == 5); P.ld = jsim_ld(P.n); P.B = B;
+    P.jerkw = c.jerk_weight;
     P.dt = c.dt; P.dl = c.dl; P.L = c.L; P.w_perp = c.w_perp; P.w_para = c.w_para;
     P.R0 = c.R[0]; P.R1 = c.R[1]; P.Rd0 = c.Rd[0]; P.Rd1 = c.Rd[1]; P.Qv = c.Q_v_yaw[0]; P.Qyaw = c.Q_v_yaw[1];
     P.Qf0 = c.Qf[0] * c.T; P.Qf1 = c.Qf[1] * c.T; P.Qf2 = c.Qf[2] * c.T; P.Qf3 = c.Qf[3] * c.T; // mpc.py:28
@@ -1331,8 +1421,11 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
     for (int pass = 0; pass < c.max_iter; ++pass) { // _iterative_linear_mpc_control, main/lib/mpc.py:231-236: one launch per pass
         P.pass = pass;
         if (ctx->use_reg_kernel) launch_reg(c.T, B, s, P, K);
-        else if (P.n <= 64) hipLaunchKernelGGL(mpc_step_kernel<1>, dim3(B), dim3(64), lds_bytes, s, P);
-        else hipLaunchKernelGGL(mpc_step_kernel<2>, dim3(B), dim3(64), lds_bytes, s, P);
+        else if (c.nx == 5) {
+            if (P.n <= 64) hipLaunchKernelGGL((mpc_step_kernel<1, true>), dim3(B), dim3(64), lds_bytes, s, P);
+            else hipLaunchKernelGGL((mpc_step_kernel<2, true>), dim3(B), dim3(64), lds_bytes, s, P);
+        } else if (P.n <= 64) hipLaunchKernelGGL((mpc_step_kernel<1, false>), dim3(B), dim3(64), lds_bytes, s, P);
+        else hipLaunchKernelGGL((mpc_step_kernel<2, false>), dim3(B), dim3(64), lds_bytes, s, P);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -1548,6 +1641,7 @@ extern "C" int jsim_mpc_update_cfg(jsim_ctx *ctx, const jsim_cfg *cfg)
 {
     if (!ctx || !cfg) return fail(ctx, -22, "jsim_mpc_update_cfg: null argument");
     if (cfg->T != ctx->cfg.T) return fail(ctx, -22, "jsim_mpc_update_cfg: the horizon cannot change (T=%d -> %d)", ctx->cfg.T, cfg->T);
+    if (cfg->nx != ctx->cfg.nx) return fail(ctx, -22, "jsim_mpc_update_cfg: NX cannot change (%d -> %d)", ctx->cfg.nx, cfg->nx);
     if (cfg->max_iter < 1 || cfg->max_iter > 16) return fail(ctx, -22, "jsim_mpc_update_cfg: MAX_ITER=%d (1..16)", cfg->max_iter);
     if (!(cfg->dt > 0) || !(cfg->dl > 0) || !(cfg->L > 0) || !(cfg->R[0] > 0) || !(cfg->R[1] > 0) || !(cfg->R_end[0] > 0) ||
         !(cfg->R_end[1] > 0))

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define JSIM_ABI_VERSION 1
+#define JSIM_ABI_VERSION 2 /* 2: jsim_cfg ends with nx, reserved_, jerk_weight */
 #define JSIM_MAX_T 48 /* two (2T)x(2T+1) fp64 tiles must fit the 160 KiB LDS of one CU */
 
 typedef struct jsim_cfg {
@@ -69,6 +69,11 @@ typedef struct jsim_cfg {
     double max_steer, max_speed, min_speed; /* Simulation.* main/lib/simulation.py:23-25 */
     double min_ref_speed;                   /* 10/3.6, main/lib/mpc.py:99 */
     double goal_dis, stop_speed;
+    int32_t nx;          /* 4: main/lib/mpc.py.  5: main/lib/mpc_jerk.py -- acceleration state x[4] with A[4][4] = 1, A[2][4] = dt,
+                          * B[4][0] = dt (:67-78), x[4,0] free (:193): the condensed QP has 2T + 1 variables (acc_0 last), oa =
+                          * u[0,:] is the input of that state; runs on the LDS-resident kernel */
+    int32_t reserved_;
+    double jerk_weight;  /* jerk_penalty_weight of (x[4,t+1] - x[4,t])^2, t < T-1 (main/lib/mpc_jerk.py:31,190); nx == 5 only */
 } jsim_cfg;
 
 typedef struct jsim_ctx jsim_ctx;
@@ -93,7 +98,7 @@ int jsim_mpc_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *pat
                   uint32_t *active_mask, int32_t *status, int32_t *n_iter, void *stream);
 
 /* Same, plus stage-level outputs for parity tests (any may be NULL):
- * xbar [B][4][T+1], ref_idx [B][T+1], H [B][2T][2T] (lower triangle valid), g [B][2T], lam [B][8T]. */
+ * xbar [B][4][T+1], ref_idx [B][T+1], H [B][n][n] (lower triangle valid), g [B][n], lam [B][8T]; n = 2T (2T + 1 with nx == 5). */
 int jsim_mpc_step_debug(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,
                         const int32_t *path_len, const double *speed, int64_t *target_ind, double *oa,
                         double *od, double *ox, double *oy, double *ov, double *oyaw, double *xref,

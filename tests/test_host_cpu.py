@@ -22,13 +22,13 @@ def test_cabi_exports_every_declared_symbol(pkg):
     so = ctypes.CDLL(lib)
     for name in declared:
         assert hasattr(so, name), name
-    assert pkg._cabi.load().jsim_abi_version() == 1
+    assert pkg._cabi.load().jsim_abi_version() == 2
 
 
 def test_cfg_struct_matches_header_layout(pkg):
     cfg = pkg._cabi.make_cfg(pkg.MPCConfig.from_json(), T=13, dt=0.2, dl=0.083, L=2.86)
-    assert ctypes.sizeof(cfg) == 8 + 8 * (3 + 2 + 2 + 2 + 2 + 4 + 2 + 3 + 3 + 1 + 2)
-    assert cfg.T == 13 and cfg.max_iter == 1
+    assert ctypes.sizeof(cfg) == 8 + 8 * (3 + 2 + 2 + 2 + 2 + 4 + 2 + 3 + 3 + 1 + 2) + 8 + 8   # .. + (nx, reserved_) + jerk_weight
+    assert cfg.T == 13 and cfg.max_iter == 1 and cfg.nx == 4
     assert list(cfg.Qf) == [1.0, 1.0, 0.0, 0.5] and list(cfg.R_end) == [10.0, 10.0]
     assert cfg.max_dsteer == np.deg2rad(30.0) and cfg.max_steer == np.deg2rad(45.0)
 
@@ -39,6 +39,10 @@ def test_create_argument_errors_without_gpu(pkg):
     cfg = pkg._cabi.make_cfg(pkg.MPCConfig.from_json(), T=49, dt=0.2, dl=0.083, L=2.86)
     assert lib.jsim_mpc_create(ctypes.byref(cfg), 0, ctypes.byref(ctx)) < 0
     assert b"T=49" in lib.jsim_last_error(None)
+    cfg = pkg._cabi.make_cfg(pkg.MPCConfig.from_json(), T=13, dt=0.2, dl=0.083, L=2.86)
+    cfg.nx = 6
+    assert lib.jsim_mpc_create(ctypes.byref(cfg), 0, ctypes.byref(ctx)) < 0
+    assert b"NX=6" in lib.jsim_last_error(None)
     assert lib.jsim_mpc_create(None, 0, ctypes.byref(ctx)) < 0
     assert lib.jsim_mpc_step(None, 1, *([None] * 16)) < 0
 

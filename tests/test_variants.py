@@ -239,3 +239,104 @@ def test_new_ref_loop_glue_speed_cutoff_mode(pkg, routes):
     assert ridx_zero[cut < batch.path_len].any() and not ridx_zero[(cut >= batch.path_len)].any()
     with pytest.raises(ValueError):
         pkg.PreTick(pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, smooth=False), mode="speed_cutoff")
+
+
+# ------------------------------------------------------------------------------------------------
+# lib.mpc_jerk: the acceleration-state variant (NX = 5, free acc_0: 2T + 1 decision variables)
+# ------------------------------------------------------------------------------------------------
+JERK_ORACLE_CFG = {"NX": 5, "w_perp": 10.0, "w_para": 1.0, "R": [0.01, 0.01], "Rd": [0.3, 1.0], "Q_v_yaw": [0.0, 0.5],
+                   "Qf": [1.0, 1.0, 0.0, 0.5], "STOP_SPEED": 0.5 / 3.6, "MAX_DECEL": -5, "JERK_WEIGHT": 1.0}
+
+
+def test_jerk_module_constants(pkg):
+    """Names and values of main/lib/mpc_jerk.py:16-39."""
+    m = pkg.mpc_jerk
+    assert (m.NX, m.NU, m.T) == (5, 2, 13) and m.MAX_DECEL == -5 and m.MAX_ACCEL == 2.0 and m.jerk_penalty_weight == 1
+    assert np.array_equal(m.Rd, np.diag([.3, 1.0])) and np.array_equal(m.Qf, np.diag([1.0, 1.0, 0., 0.5, 0]) * 13)
+    assert m.config.NX == 5 and m.config.w_perp == 10.0 and m.config.JERK_WEIGHT == 1.0
+    with pytest.raises(ValueError):
+        from dataclasses import asdict
+        import json, tempfile, os
+        bad = dict(asdict(pkg.MPCConfig()), NX=6)
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(bad, f)
+        try:
+            pkg.MPCConfig.from_json(f.name)
+        finally:
+            os.unlink(f.name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", (13, 20, 40))
+def test_jerk_variant_gpu_vs_oracle(pkg, oracle, routes, T):
+    """The HIP path with 2T + 1 variables against the oracle's (itself pinned by the variant's sparse form,
+    tests/test_oracle_qp.py): statuses, reference window, u*, predicted states, active sets; the condensed (H, g) of a few
+    egos.  T = 40 takes the two-rows-per-lane instantiation (81 variables)."""
+    from dataclasses import replace
+    B = 64 if T <= 20 else 32
+    cfg = replace(pkg.mpc_jerk.config, T=T)
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=13, truncate=True, near_end_frac=0.25)
+    vmax = np.full(B, cfg.MAX_SPEED)                    # x[2,:] <= Simulation.MAX_SPEED (mpc_jerk.py:194)
+    batch.x0[3, 2] = cfg.MAX_SPEED + 0.5                # infeasible constant row
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=vmax, smooth=False, config=cfg)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    n = 2 * T + 1
+    f = dict(dtype=torch.float64, device=eng.device)
+    dbg = {"H": torch.zeros(B, n, n, **f), "g": torch.zeros(B, n, **f), "lam": torch.zeros(B, 8 * T, **f)}
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device), debug=dbg)
+    torch.cuda.synchronize()
+    p = oracle.make_params(T=T, config=JERK_ORACLE_CFG)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    ref = oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, vmax, cx, cy, cyaw, off, batch.target_ind,
+                                batch.oa, batch.od)
+    st = eng.status.cpu().numpy()
+    assert np.array_equal(st, ref["status"]) and st[3] == 1
+    assert np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy(), ref["xref"])
+    ok = st == 0
+    assert ok.sum() >= B - 6
+    err = max(np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max(), np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max())
+    print(f"T={T}: max|du|={err:.2e}, mean n_iter {ref['n_iter'][ok].mean():.1f}, identical n_iter "
+          f"{(eng.n_iter.cpu().numpy() == ref['n_iter']).mean() * 100:.0f} %")
+    assert err <= 1e-4 and err <= 1e-6, err
+    for name in ("ox", "oy", "ov", "oyaw"):
+        np.testing.assert_allclose(getattr(eng, name).cpu().numpy()[ok], ref[name][ok], rtol=0, atol=1e-6)
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
+    assert np.unpackbits(ref["active_mask"].view(np.uint8), axis=1).sum() > B     # the constraints do bind
+    H = dbg["H"].cpu().numpy(); g = dbg["g"].cpu().numpy()
+    for b in np.flatnonzero(ok)[:8]:
+        o = off[batch.path_id[b]]
+        r = oracle.mpc_step(p, (batch.x0[b, 0], batch.x0[b, 1], batch.x0[b, 3], batch.x0[b, 2]),
+                            cx[o:o + batch.path_len[b]], cy[o:o + batch.path_len[b]], cyaw[o:o + batch.path_len[b]],
+                            int(batch.target_ind[b]), vmax[b], oa=batch.oa[b], od=batch.od[b], want_qp=True)
+        Hl = np.tril(H[b]); Hl = Hl + np.tril(Hl, -1).T
+        assert np.abs(Hl - r["H"]).max() <= 1e-9 * np.abs(r["H"]).max()
+        assert np.abs(g[b] - r["g"]).max() <= 1e-9 * max(1.0, np.abs(r["g"]).max())
+    # the acceleration state matters: the stock controller with the same weights gives another answer
+    plain = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=vmax, smooth=False, config=replace(cfg, NX=4))
+    plain.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    plain.solve(torch.from_numpy(batch.x0).to(eng.device))
+    assert float((plain.oa - eng.oa)[torch.from_numpy(ok).to(eng.device)].abs().max()) > 1e-2
+
+
+@pytest.mark.gpu
+def test_jerk_dropin_closed_loop(pkg, oracle, routes):
+    """lib.mpc_jerk.MPC(cx, cy, cyaw, dl, car_dimensions, dt) through 25 ticks of the per-vehicle loop against the oracle
+    driven the same way (warm start and target index carried; plant = Simulation.step)."""
+    m = pkg.mpc_jerk
+    r = routes[2].copy()
+    mpc = m.MPC(cx=r[:, 0], cy=r[:, 1], cyaw=r[:, 2].copy(), dl=pkg.synth.DL, car_dimensions=pkg.BicycleModelDimensions())
+    p = oracle.make_params(T=13, config=JERK_ORACLE_CFG)
+    state = np.array([r[5, 0], r[5, 1], 0.0, r[5, 2]])             # x, y, v, yaw
+    tind, oa, od = 0, None, None
+    for k in range(25):
+        st = pkg.State(x=state[0], y=state[1], yaw=state[3], v=state[2])
+        di, ai = mpc.step(st)
+        ref = oracle.mpc_step(p, (state[0], state[1], state[3], state[2]), r[:, 0], r[:, 1], r[:, 2], tind, 30 / 3.6, oa=oa, od=od)
+        assert mpc.status == ref["status"] == 0
+        assert mpc.target_ind == ref["target_ind"]
+        assert abs(di - ref["od"][0]) <= 1e-7 and abs(ai - ref["oa"][0]) <= 1e-7, (k, di, ai)
+        assert mpc.active_constraints == ref["active"]
+        tind, oa, od = ref["target_ind"], ref["oa"], ref["od"]
+        state = oracle.plant_step(p, state, ref["oa"][0], ref["od"][0])
+    assert state[2] > 1.0                                          # it drove off
