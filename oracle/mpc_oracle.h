@@ -17,6 +17,8 @@
  *   main/lib/mpc.py:284-330   MPC.step / get_current_xref_deviation / is_goal
  *   main/lib/mpc_with_speed.py:85-110,276-282  the variant's speed reference cv (orc_mpc_step_cv); its other
  *                             differences are parameter values (weights, MAX_DECEL, speed limit)
+ *   main/lib/mpc_jerk.py:59-83,144-199  the acceleration-state variant (orc_params.nx == 5): 5x5 model, free x[4,0]
+ *                             carried as decision variable 2T, jerk cost; built by the same generic condensation
  *   main/lib/trajectories.py:100-126  calc_nearest_index_in_direction
  *   main/lib/simulation.py:22-47      Simulation.step (plant, clamps)
  *   main/bicycle/main.py:28-41        Bicycle.step (explicit Euler kinematic bicycle)

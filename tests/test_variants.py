@@ -266,6 +266,39 @@ def test_jerk_module_constants(pkg):
             os.unlink(f.name)
 
 
+def test_jerk_golden_from_reference_functions(pkg, oracle, routes):
+    """What the reference's own lib.mpc_jerk functions returned (tests/golden/make_golden_jerk.py): module constants; the
+    5x5 / 5x2 / 5 linear model against the numpy restatement that pins the oracle's condensed QP (so the chain reference ->
+    restatement -> oracle -> HIP is closed for the model); the five-row reference window and rollout against the oracle's
+    stages (rows 0..3 identical to lib.mpc's, the fifth rows zero)."""
+    import qp_sparse_numpy as QS
+    g = load_golden("variant_jerk.npz")
+    m = pkg.mpc_jerk
+    assert (int(g["c_NX"]), int(g["c_NU"]), int(g["c_T"])) == (m.NX, m.NU, m.T)
+    assert np.array_equal(g["c_R"], np.diag(m.R)) and np.array_equal(g["c_Rd"], np.diag(m.Rd))
+    assert np.array_equal(g["c_Q_v_yaw"], np.diag(m.Q_v_yaw)) and np.array_equal(g["c_Qf_scaled"], np.diag(m.Qf))
+    assert float(g["c_MAX_DECEL"]) == m.MAX_DECEL and float(g["c_MAX_ACCEL"]) == m.MAX_ACCEL
+    assert float(g["c_MAX_DSTEER"]) == m.MAX_DSTEER and float(g["c_jerk_penalty_weight"]) == m.jerk_penalty_weight
+    assert float(g["c_STOP_SPEED"]) == m.STOP_SPEED and float(g["c_GOAL_DIS"]) == m.GOAL_DIS
+    for k in range(len(g["lm_v"])):
+        A, B, C = QS.linear_model_jerk(g["lm_v"][k], g["lm_phi"][k], g["lm_delta"][k], pkg.synth.DT, 2.86)
+        np.testing.assert_allclose(A, g["lm_A"][k], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(B, g["lm_B"][k], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(C, g["lm_C"][k], rtol=0, atol=1e-15)
+    assert np.all(g["lm_A"][:, 4, 4] == 1.0) and np.all(g["lm_A"][:, 2, 4] == pkg.synth.DT) and np.all(g["lm_B"][:, 4, 0] == pkg.synth.DT)
+    p = oracle.make_params(T=13, config=JERK_ORACLE_CFG)
+    for b in range(len(g["x0"])):
+        r = routes[int(g["path_id"][b])][: int(g["path_len"][b])]
+        x, y, v, yaw = g["x0"][b]
+        st_, xref, idx, rend, tind = oracle.calc_ref_trajectory(p, x, y, v, r[:, 0], r[:, 1], r[:, 2], int(g["target_ind_in"][b]))
+        assert st_ == 0 and tind == g["target_ind_out"][b]
+        np.testing.assert_array_equal(xref, g["xref"][b][:4])
+        assert np.array_equal(rend.astype(bool), g["reaches_end"][b])
+        xbar = oracle.predict_motion(p, g["x0"][b], g["oa"][b], g["od"][b])
+        np.testing.assert_allclose(xbar, g["xbar"][b][:4], rtol=0, atol=1e-12)
+    assert not g["xref"][:, 4].any() and not g["xbar"][:, 4].any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("T", (13, 20, 40))
 def test_jerk_variant_gpu_vs_oracle(pkg, oracle, routes, T):
