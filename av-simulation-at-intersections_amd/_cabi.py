@@ -11,7 +11,7 @@ import os
 from .config import MPCConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjsim_mpc.so")
+LIB_PATH = os.environ.get("JSIM_LIB_PATH") or os.path.join(_HERE, "libjsim_mpc.so")  # JSIM_LIB_PATH: A/B runs of diagnostic builds
 ABI_VERSION = 2
 
 
