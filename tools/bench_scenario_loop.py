@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Diagnostic: the WHOLE per-vehicle loop of main/scenarios/mpc_intersection.py:99-163 on the device for a batch -- obstacle
+get() -> prediction -> progress index / resample / collision / cut-off -> MPC.step -> plant, goal -> obstacle step() -- at
+config 3's shape (default 4096 egos, T = 30, four scripted obstacle vehicles, FRAME_WINDOW = 10), one set of launches per tick.
+Prints ticks/s, MPC steps/s and how the tick divides between the loop glue (f1) and the MPC step.
+
+    python tools/bench_scenario_loop.py [B=4096] [T=30] [ticks=60]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+pkg = importlib.import_module("av-simulation-at-intersections_amd")
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+S = pkg.synth
+routes = S.make_route_table()
+for r in routes:
+    S.smooth_yaw_inplace(r[:, 2])
+batch = S.make_ego_batch(routes, B, T, seed=1)
+eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smooth=False)
+eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+x0 = torch.from_numpy(batch.x0).cuda()
+specs = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None), dict(direction=-1, turning=True, speed=20 / 3.6, offset=6.0),
+         dict(direction=1, turning=True, speed=15 / 3.6, offset=12.0), dict(direction=-1, turning=False, speed=25 / 3.6, offset=3.0)]
+sc = pkg.ScenarioLoop(eng, x0, specs, max_age=400)
+
+
+def timed(fn, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for _ in range(10):
+    sc.tick()
+ms_tick = timed(sc.tick, K)
+cut = int((eng.path_len.cpu().numpy() < batch.path_len).sum())
+
+
+def glue():
+    g = sc.obst.get(step=False)
+    sc.pre.predict(g)
+    sc.pre.run(sc.loop.x0)
+
+
+ms_glue = timed(glue, K)
+ms_mpc = timed(sc.loop.tick, K)
+print(f"{B} egos, T = {T}, {len(specs)} obstacle vehicles, FRAME_WINDOW = {sc.pre.frame_window}, {sc.pre.n_steps} predicted frames:")
+print(f"  whole loop tick            {ms_tick:8.3f} ms  -> {B / ms_tick * 1e3 / 1e6:.2f} M MPC steps/s with the loop glue on the device")
+print(f"  loop glue alone (f1)       {ms_glue:8.3f} ms  ({100 * ms_glue / ms_tick:.0f} % of the tick; obstacle get + prediction + pre-tick kernel)")
+print(f"  MPC step + advance alone   {ms_mpc:8.3f} ms")
+print(f"  egos whose path is cut off by a predicted collision right now: {cut} of {B}")
