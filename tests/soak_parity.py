@@ -2,9 +2,9 @@
 """Diagnostic soak: the HIP step against the CPU oracle over many seeded ego batches (more than the test suite can
 afford), every horizon that has a register kernel plus one that takes the LDS kernel.  Prints, per horizon, the worst
 |du|, how many active sets / statuses / target indices differ and how often the iteration count is identical.
-Uses oracle/ as the checker only (tools/ is diagnostics, like tests/).
+Test infrastructure (lives under tests/ because it loads oracle/ as the checker; not collected by pytest -- run by hand):
 
-    python tools/soak_parity.py [seeds=8] [B=512]
+    python tests/soak_parity.py [seeds=8] [B=512]
 """
 import importlib
 import os
