@@ -62,7 +62,7 @@ Reading: one wave per CU, ~13k VALU wave-instructions per step at ~5.3 cycles ea
 instruction of a lone wave issues in >= 5.3 cycles, a dependent FMA chain in 8.3, FMA->readlane->FMA in 26, a uniform
 branch in ~40, a ds_write_b128 in 25): the path is bound by the issue latency of a single wavefront (SURVEY D6), not by
 HBM and not by MFMA throughput.  The launch time is set by the slowest of the 256 egos (tools/wave_span.py: the mean
-step takes 55.7k + 6.06k * n_iter cycles, the slowest ego averages 21 iterations against a fleet mean of 10.9).
+step takes 57.3k + 5.67k * n_iter cycles, the slowest ego averages 21 iterations against a fleet mean of 10.9).
 """
 for t in tags[1:]:
     p = load(t)
