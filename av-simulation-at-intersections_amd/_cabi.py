@@ -32,7 +32,7 @@ class JsimCfg(C.Structure):
 EXPORTS = (
     "jsim_abi_version", "jsim_last_error", "jsim_mpc_create", "jsim_mpc_destroy", "jsim_mpc_set_paths",
     "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance", "jsim_mpc_run_ticks",
-    "jsim_loop_set_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
+    "jsim_loop_set_geometry", "jsim_loop_set_obstacle_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
     "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_mpc_set_ego_config", "jsim_loop_obstacles",
     "jsim_mpc_xref_deviation_goal",
 )
@@ -75,6 +75,8 @@ def load() -> C.CDLL:
     lib.jsim_loop_advance.argtypes = [vp, i32] + [vp] * 11 + [i32, vp, vp, i32, vp, vp]
     lib.jsim_loop_set_geometry.restype = C.c_int
     lib.jsim_loop_set_geometry.argtypes = [vp, dbl, dbl, dbl]
+    lib.jsim_loop_set_obstacle_geometry.restype = C.c_int
+    lib.jsim_loop_set_obstacle_geometry.argtypes = [vp, dbl, dbl, dbl, dbl]
     lib.jsim_loop_predict_obstacles.restype = C.c_int
     lib.jsim_loop_predict_obstacles.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.jsim_loop_pre_tick.restype = C.c_int

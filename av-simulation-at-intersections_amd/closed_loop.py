@@ -102,7 +102,12 @@ class PreTick:
     engine must carry a speed reference (`cv`)."""
 
     def __init__(self, engine: BatchedMPC, frame_window: int = 10, time_horizon: float = 7.0, car_width: float = 2.0,
-                 extra_length: float = 0.64, mode: str = "truncate"):
+                 extra_length: float = 0.64, mode: str = "truncate", obstacle_dims: Optional[dict] = None,
+                 margin_factor: int = 4):
+        """obstacle_dims = dict(L=1.0, width=0.45, extra_length=0.64) gives the obstacles their own shape (the cyclist's
+        BicycleRealDimensions of main/scenarios/overtaking_cyclist_bidirectional_road.py: prediction with that wheelbase,
+        `check_collision_moving_bicycle`); margin_factor: EXTRA_CUTOFF_MARGIN = margin_factor * ceil(radius / dl) (4 in
+        mpc_intersection.py:88-89, 2 in the cyclist scenario :94-95)."""
         if mode not in ("truncate", "speed_cutoff"):
             raise ValueError("mode must be 'truncate' or 'speed_cutoff'")
         if mode == "speed_cutoff" and engine.cv is None:
@@ -113,8 +118,13 @@ class PreTick:
         self.radius, (c0, c1) = car_circles(eng.L, car_width, extra_length)
         self.frame_window = int(frame_window)
         self.n_steps = int(math.ceil(time_horizon / eng.dt - 1e-9))          # len(np.arange(0, horizon, dt))
-        self.margin = 4 * int(math.ceil(self.radius / eng.dl))               # EXTRA_CUTOFF_MARGIN, :88-89
+        self.margin = int(margin_factor) * int(math.ceil(self.radius / eng.dl))   # EXTRA_CUTOFF_MARGIN, :88-89
         _cabi.check(eng.lib.jsim_loop_set_geometry(eng._ctx, c0, c1, self.radius), eng._ctx, "jsim_loop_set_geometry")
+        if obstacle_dims is not None:
+            oL = float(obstacle_dims["L"])
+            orad, (o0, o1) = car_circles(oL, float(obstacle_dims.get("width", 2.0)), float(obstacle_dims.get("extra_length", 0.64)))
+            _cabi.check(eng.lib.jsim_loop_set_obstacle_geometry(eng._ctx, o0, o1, orad, oL), eng._ctx,
+                        "jsim_loop_set_obstacle_geometry")
         dev, B = eng.device, eng.B
         self.traj_idx = torch.zeros(B, dtype=torch.int64, device=dev)
         self.prev_len = torch.full((B,), -1, dtype=torch.int32, device=dev)   # tmp_trajectory is None

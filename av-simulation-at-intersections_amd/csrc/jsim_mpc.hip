@@ -1225,6 +1225,8 @@ struct jsim_ctx {
     double *h_cx, *h_cy, *h_cyaw;
     int have_geom;
     double cc0, cc1, col_radius;
+    double occ0, occ1, ocol_radius, oL; // the obstacles' circles / wheelbase (jsim_loop_set_obstacle_geometry); default: the ego's
+    int have_ogeom;
     double2 *d_pcc;
     double2 *d_pred_cc;
     int pred_n_obs, pred_n_steps;
@@ -1571,8 +1573,17 @@ extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_
     if (!(radius > 0)) return fail(ctx, -22, "jsim_loop_set_geometry: radius must be positive");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->cc0 = cc_front; ctx->cc1 = cc_rear; ctx->col_radius = radius; ctx->have_geom = 1;
+    if (!ctx->have_ogeom) { ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = ctx->cfg.L; }
     if (!ctx->d_pred_cc) HIP_TRY(ctx, hipMalloc(&ctx->d_pred_cc, sizeof(double2) * JSIM_MAX_OBS * JSIM_MAX_PRED * 2));
     return upload_circle_centres(ctx);
+}
+
+extern "C" int jsim_loop_set_obstacle_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius, double wheelbase)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_set_obstacle_geometry: null ctx");
+    if (!(radius > 0) || !(wheelbase > 0)) return fail(ctx, -22, "jsim_loop_set_obstacle_geometry: radius and wheelbase must be positive");
+    ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = wheelbase; ctx->have_ogeom = 1;
+    return 0;
 }
 
 extern "C" int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const double *obst, int32_t n_steps, double *pred,
@@ -1585,7 +1596,7 @@ extern "C" int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const d
     ctx->pred_n_obs = n_obs; ctx->pred_n_steps = n_steps;
     if (n_obs == 0) return 0;
     if (!obst || !pred) return fail(ctx, -22, "jsim_loop_predict_obstacles: null device pointer");
-    ObsP P = {n_obs, n_steps, ctx->cfg.dt, ctx->cfg.L, ctx->cc0, ctx->cc1, obst, pred, ctx->d_pred_cc};
+    ObsP P = {n_obs, n_steps, ctx->cfg.dt, ctx->oL, ctx->occ0, ctx->occ1, obst, pred, ctx->d_pred_cc};
     hipLaunchKernelGGL(obstacle_predict_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -1607,7 +1618,7 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
     PreP P;
     memset(&P, 0, sizeof(P));
     P.B = B; P.n_obs = ctx->pred_n_obs; P.n_steps = ctx->pred_n_steps; P.frame_window = frame_window; P.margin = margin;
-    P.dt = c.dt; P.max_accel = c.max_accel; P.max_speed = c.max_speed; P.thr = 2.0 * ctx->col_radius;
+    P.dt = c.dt; P.max_accel = c.max_accel; P.max_speed = c.max_speed; P.thr = ctx->col_radius + ctx->ocol_radius; // min_distance: 2 * radius, or car radius + bicycle radius
     P.pxy = ctx->d_pxy; P.pcc = ctx->d_pcc; P.poff = ctx->d_poff; P.pred_cc = ctx->d_pred_cc;
     P.x0 = x0; P.path_id = path_id; P.traj_idx = (long long *)traj_idx; P.prev_path_len = prev_path_len; P.path_len = path_len;
     P.col_flag = col_flag; P.col_xy = col_xy; P.first_idx = first_idx; P.status = status;

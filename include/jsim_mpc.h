@@ -158,6 +158,12 @@ int jsim_mpc_set_ego_config(jsim_ctx *ctx, const double *cfg);
  *   exactly what jsim_mpc_step takes.  prev_path_len [B]: previous tick's path_len, -1 before the first tick.
  *   status: 0 ok, 2 nearest-index anomaly, 4 resampled path longer than the kernel's 320-point table. */
 int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius);
+/* Obstacles of another shape than the ego (main/scenarios/overtaking_cyclist_bidirectional_road.py:122-133: the cyclist's
+ * BicycleRealDimensions): their two circles and wheelbase -- used by the prediction (MovingObstaclesPrediction(...,
+ * car_dimensions=bicycle_dimensions)) and by the collision rows of check_collision_moving_bicycle,
+ * main/lib/collision_avoidance.py:126-166 (min_distance = car radius + bicycle radius, same row order).  Without this call
+ * the obstacles have the ego's geometry (check_collision_moving_cars). */
+int jsim_loop_set_obstacle_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius, double wheelbase);
 /* Scripted obstacle vehicles of main/lib/moving_obstacles.py -- MovingObstacleTIntersection (:166-232, kind 0),
  * MovingObstacleRoundabout (:28-124, kind 1), MovingObstacleArterial (:126-164, kind 2): state [n_obs][4] = (xc, yc, theta,
  * counter) in/out, param [n_obs][8] = (direction +-1, turning 0/1, speed, offset seconds (<= 0: none), x_turn, dt, kind,

@@ -80,20 +80,29 @@ def predict_obstacle(x, y, v, yaw, a, steer, dt: float = DT, L: float = 2.86, ho
     return out
 
 
+def _pair_geometry(L: float, obst_dims):
+    """(min_distance, ego circle offsets, obstacle circle offsets): two cars (collision_avoidance.py:95), or a car and an
+    obstacle of another shape, obst_dims = (L, width, extra_length) -- check_collision_moving_bicycle, :137."""
+    radius, offs = car_circles(L)
+    if obst_dims is None:
+        return 2 * radius, offs, offs
+    orad, ooffs = car_circles(*obst_dims)
+    return radius + orad, offs, ooffs
+
+
 def first_collision(res: np.ndarray, detailed: np.ndarray, preds: Sequence[np.ndarray], L: float = 2.86,
-                    frame_window: int = FRAME_WINDOW) -> Optional[Tuple[float, float, int]]:
+                    frame_window: int = FRAME_WINDOW, obst_dims=None) -> Optional[Tuple[float, float, int]]:
     """collision_avoidance.py:85-124.  res: resampled ego path (n_res, 3); detailed: the ego path from its progress
     index (n, 3); preds: predicted obstacle trajectories (each (P, 3)).
     Row order of the reference's pair table: frame f, then ego circle a, then obstacle copy c = o * (2w+1) + (off + w)
     with off = -w..w, then obstacle circle b.  Copy (o, off) at frame f shows sample clamp(min(f, P-1) - off, 0, P-1)."""
     if len(preds) == 0:
         return None
-    radius, offs = car_circles(L)
-    thr = 2 * radius
+    thr, offs, ooffs = _pair_geometry(L, obst_dims)
     P = len(preds[0])
     F = max(len(res), max(len(p) for p in preds))
     ego_cc = [circle_centres(res, xo) for xo in offs]
-    obs_cc = [[circle_centres(p, xo) for xo in offs] for p in preds]
+    obs_cc = [[circle_centres(p, xo) for xo in ooffs] for p in preds]
     hit = None
     for f in range(F):
         fa = min(f, len(res) - 1)
@@ -135,12 +144,11 @@ def first_collision(res: np.ndarray, detailed: np.ndarray, preds: Sequence[np.nd
     return float(detailed[first, 0]), float(detailed[first, 1]), first
 
 
-def first_collision_fast(res, detailed, preds, L=2.86, frame_window=FRAME_WINDOW):
+def first_collision_fast(res, detailed, preds, L=2.86, frame_window=FRAME_WINDOW, obst_dims=None):
     """Vectorised form of first_collision (same row order), used for the bulk of the tests."""
     if len(preds) == 0:
         return None
-    radius, offs = car_circles(L)
-    thr = 2 * radius
+    thr, offs, ooffs = _pair_geometry(L, obst_dims)
     P = len(preds[0])
     F = max(len(res), max(len(p) for p in preds))
     w = frame_window
@@ -149,7 +157,7 @@ def first_collision_fast(res, detailed, preds, L=2.86, frame_window=FRAME_WINDOW
     offv = np.arange(-w, w + 1)
     j = np.clip(fo[:, None] - offv[None, :], 0, P - 1)                       # [F, 2w+1]
     ego = np.stack([circle_centres(res, xo)[fa] for xo in offs], axis=1)      # [F, a, 2]
-    obs = np.stack([np.stack([circle_centres(p, xo)[j] for xo in offs], axis=2) for p in preds], axis=1)  # [F, o, off, b, 2]
+    obs = np.stack([np.stack([circle_centres(p, xo)[j] for xo in ooffs], axis=2) for p in preds], axis=1)  # [F, o, off, b, 2]
     d = ego[:, :, None, None, None, :] - obs[:, None, :, :, :, :]             # [F, a, o, off, b, 2]
     m = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) <= thr
     flat = m.reshape(-1)
@@ -180,9 +188,12 @@ def extra_cutoff_margin(dl: float, L: float = 2.86) -> int:
 
 
 def loop_pre_tick(state_xyyawv, traj_agent_idx: int, prev_path_len: Optional[int], full: np.ndarray,
-                  obstacles: Sequence[Sequence[float]], dl: float, L: float = 2.86, dt: float = DT):
+                  obstacles: Sequence[Sequence[float]], dl: float, L: float = 2.86, dt: float = DT, obst_dims=None,
+                  margin_factor: int = 4, frame_window: int = FRAME_WINDOW):
     """mpc_intersection.py:104-140 for one ego: returns (status, traj_agent_idx, path_len, collision_xy or None).
-    obstacles: (x, y, v, yaw, a, steer) tuples as MovingObstacle*.get() returns them."""
+    obstacles: (x, y, v, yaw, a, steer) tuples as MovingObstacle*.get() returns them.  obst_dims = (L, width,
+    extra_length) of obstacles shaped unlike the ego and margin_factor = 2: the same glue in
+    scenarios/overtaking_cyclist_bidirectional_road.py:94-95,122-133,221-240."""
     x, y, yaw, v = state_xyyawv
     M = len(full)
     # :106-109  (rows of a path are distinct points, so "row differs from the last row" == "index differs")
@@ -193,11 +204,11 @@ def loop_pre_tick(state_xyyawv, traj_agent_idx: int, prev_path_len: Optional[int
         traj_agent_idx = idx
     detailed = full[traj_agent_idx:]
     res = detailed[resample_mask(detailed[:, :2], ego_resample_dl(len(detailed), v, dt))]
-    preds = [predict_obstacle(*o, dt=dt, L=L) for o in obstacles]
-    col = first_collision_fast(res, detailed, preds, L=L)
+    preds = [predict_obstacle(*o, dt=dt, L=L if obst_dims is None else obst_dims[0]) for o in obstacles]
+    col = first_collision_fast(res, detailed, preds, L=L, frame_window=frame_window, obst_dims=obst_dims)
     if col is None:
         return 0, traj_agent_idx, M, None
     c = cutoff_index(full, col[0], col[1])
     assert c is not None
-    cut = max(traj_agent_idx + 1, c - extra_cutoff_margin(dl, L))
+    cut = max(traj_agent_idx + 1, c - (extra_cutoff_margin(dl, L) // 4) * margin_factor)
     return 0, traj_agent_idx, cut, (col[0], col[1])

@@ -372,6 +372,41 @@ def test_pre_tick_vs_reference_golden(pkg, routes):
     assert n_col >= 100
 
 
+def test_pre_tick_bicycle_obstacles_vs_reference_golden(pkg, routes):
+    """The loop glue with obstacles shaped unlike the ego (jsim_loop_set_obstacle_geometry): the cyclist of
+    scenarios/overtaking_cyclist_bidirectional_road.py -- prediction with the bicycle's wheelbase,
+    check_collision_moving_bicycle, margin 2 * ceil(radius / dl) -- against what the reference's functions returned."""
+    g = load_golden("loop_bicycle.npz")
+    eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=float(g["dl"]), T=13, smooth=False)
+    pre = pkg.PreTick(eng, obstacle_dims=dict(L=1.0, width=0.45, extra_length=0.64), margin_factor=2)
+    assert pre.margin == int(g["margin"]) and pre.radius == float(g["car_radius"])
+    x0 = torch.zeros(1, 4, dtype=torch.float64, device=eng.device)
+    n_col = 0
+    for k in range(len(g["route"])):
+        rid, idx, v = int(g["route"][k]), int(g["idx"][k]), float(g["v"][k])
+        eng.path_id.fill_(rid)
+        full = routes[rid]
+        x0[0, 0], x0[0, 1], x0[0, 2], x0[0, 3] = full[idx, 0], full[idx, 1], v, full[idx, 2]
+        pre.traj_idx.fill_(idx)
+        pre.prev_len.fill_(idx + 1)
+        pred = pre.predict(torch.from_numpy(np.ascontiguousarray(g["obst"][k])).to(eng.device))
+        pre.run(x0)
+        torch.cuda.synchronize()
+        assert int(pre.status.item()) == 0 and int(pre.traj_idx.item()) == idx
+        np.testing.assert_allclose(pred.cpu().numpy(), g["pred"][k], rtol=0, atol=1e-12)
+        flag, cx, cy, first = g["col"][k]
+        assert int(pre.col_flag.item()) == int(flag)
+        assert int(eng.path_len.item()) == int(g["cutoff"][k])
+        if flag:
+            n_col += 1
+            assert int(pre.first_idx.item()) == int(first)
+            assert tuple(pre.col_xy[0].cpu().numpy()) == (cx, cy)
+    assert 40 <= n_col <= 110
+    # the same cases with the ego's own shape for the obstacles give other answers (the geometry does matter)
+    pre2 = pkg.PreTick(pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=float(g["dl"]), T=13, smooth=False))
+    assert pre2.margin == 2 * pre.margin
+
+
 def test_closed_loop_config1_replay(pkg, routes):
     """Config 1 (mpc_intersection, 1 ego, stock T = 13): every tick of the recorded reference loop replayed through the GPU
     loop glue + MPC step: progress index, cut-off and target_ind bit-exact, controls within 1e-7 of the recorded ones."""

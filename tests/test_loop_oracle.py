@@ -72,3 +72,39 @@ def test_closed_loop_pre_tick_matches_reference_loop(LO, routes):
         assert abs(r["od"][0] - delta) <= 1e-12 and abs(r["oa"][0] - accel) <= 1e-12
         oa, od = r["oa"], r["od"]
     assert n_cut >= 20 and bool(g["reached_goal"])
+
+
+BIKE = (1.0, 0.45, 0.64)     # BicycleRealDimensions: wheelbase, bounding-box width, extra length (lib/car_dimensions.py:92-100)
+
+
+def test_bicycle_obstacle_glue_vs_reference(LO, routes):
+    """The same glue with an obstacle of another shape (the cyclist of scenarios/overtaking_cyclist_bidirectional_road.py):
+    prediction with the bicycle's wheelbase, check_collision_moving_bicycle (min_distance = car radius + bicycle radius,
+    the bicycle's circle centres), cut-off with the scenario's margin of 2 * ceil(radius / dl)."""
+    g = load_golden("loop_bicycle.npz")
+    orad, ooffs = LO.car_circles(*BIKE)
+    assert orad == float(g["bike_radius"]) and float(g["bike_L"]) == BIKE[0]
+    np.testing.assert_allclose(np.array([[ooffs[0], 0.0], [ooffs[1], 0.0]]), g["bike_circle_centers"], rtol=0, atol=1e-15)
+    assert (LO.extra_cutoff_margin(float(g["dl"])) // 4) * 2 == int(g["margin"])
+    n_col = 0
+    for k in range(len(g["route"])):
+        full = routes[int(g["route"][k])]
+        idx, v = int(g["idx"][k]), float(g["v"][k])
+        detailed = full[idx:]
+        res = detailed[LO.resample_mask(detailed[:, :2], LO.ego_resample_dl(len(detailed), v))]
+        preds = [LO.predict_obstacle(*o, L=BIKE[0]) for o in g["obst"][k]]
+        np.testing.assert_allclose(np.stack(preds), g["pred"][k], rtol=0, atol=1e-12)
+        col = LO.first_collision_fast(res, detailed, list(g["pred"][k]), obst_dims=BIKE)
+        flag, cx, cy, first = g["col"][k]
+        if flag == 0:
+            assert col is None
+        else:
+            n_col += 1
+            assert col is not None and col[2] == int(first) and col[0] == cx and col[1] == cy
+            if k % 8 == 0:
+                assert LO.first_collision(res, detailed, list(g["pred"][k]), obst_dims=BIKE) == col
+        x, y, yaw = full[idx]
+        st, i2, plen, _ = LO.loop_pre_tick((x, y, yaw, v), idx, idx + 1, full, g["obst"][k], float(g["dl"]), obst_dims=BIKE,
+                                           margin_factor=2)
+        assert st == 0 and i2 == idx and plen == int(g["cutoff"][k])
+    assert 40 <= n_col <= 110
