@@ -486,6 +486,55 @@ def test_degenerate_paths_and_positions(pkg, oracle):
     assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
 
 
+@pytest.mark.parametrize("T", (13, 20, 30, 40, 25))
+def test_nearest_index_on_self_approaching_paths(pkg, oracle, T):
+    """Paths that come back to themselves: hairpins whose return leg passes the ego (the nearest points sit 600 indices
+    ahead of the remembered index), a loop that closes on its start, a double hairpin, and a long straight; egos at every
+    phase of the scan's 256-point trips.  The reference scans the whole remaining path (trajectories.py:100-126), so must
+    every kernel: every index and status against the oracle.  (Written for a pruned scan -- bounding circles per 256
+    points against the wave-minimum of the lanes' third-best distance; exact on these cases, but its scalar loads and the
+    extra reduction cost what the skipped chunks saved: T = 20 +-0, T = 30 +2.6 %, T = 40 -3.5 %.  Not shipped.)"""
+    dl = pkg.synth.DL
+    def polyline(pts, n):
+        pts = np.asarray(pts, dtype=float)
+        seg = np.r_[0.0, np.cumsum(np.hypot(*np.diff(pts, axis=0).T))]
+        s = np.linspace(0.0, seg[-1], n)
+        x = np.interp(s, seg, pts[:, 0]); y = np.interp(s, seg, pts[:, 1])
+        yaw = np.arctan2(np.gradient(y), np.gradient(x))
+        r = np.stack([x, y, yaw], axis=1)
+        pkg.synth.smooth_yaw_inplace(r[:, 2])
+        return r
+    paths = [polyline([(0, 0), (28, 0), (28, 1.2), (0, 1.2)], 700),                       # hairpin, legs 1.2 m apart
+             polyline([(0, 0), (60, 0)], 720),                                            # straight
+             polyline([(0, 0), (15, 0), (15, 15), (0, 15), (0, 0.6), (10, 0.6)], 900),    # loop closing on its start
+             polyline([(0, 0), (20, 0), (20, 0.7), (1, 0.7), (1, 1.4), (20, 1.4)], 900)]  # double hairpin
+    rng = np.random.default_rng(3)
+    B = 96
+    pid = rng.integers(0, len(paths), B).astype(np.int32)
+    plen = np.array([len(paths[i]) for i in pid], dtype=np.int32)
+    tind = np.zeros(B, dtype=np.int64)
+    x0 = np.zeros((B, 4))
+    for b in range(B):
+        r = paths[pid[b]]
+        s0 = int(rng.integers(0, 300)) if b % 3 else 0
+        tind[b] = s0
+        j = int(rng.integers(s0, len(r) - 1)) if b % 2 else int(min(s0 + rng.integers(0, 40), len(r) - 2))
+        x0[b] = (r[j, 0] + rng.normal(0, 0.25), r[j, 1] + rng.normal(0, 0.25), rng.uniform(0, 8), r[j, 2])
+    eng = pkg.BatchedMPC(paths, pid, dl=dl, T=T, smooth=False)
+    eng.load_state(tind, np.zeros((B, T)), np.zeros((B, T)), plen)
+    eng.solve(torch.from_numpy(x0).to(eng.device))
+    torch.cuda.synchronize()
+    p = oracle.make_params(T=T)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(paths)
+    ref = oracle.mpc_step_batch(p, x0, pid, plen, np.full(B, 30 / 3.6), cx, cy, cyaw, off, tind, np.zeros((B, T)), np.zeros((B, T)))
+    assert np.array_equal(eng.status.cpu().numpy(), ref["status"])
+    use = ref["status"] != 2
+    assert np.array_equal(eng.target_ind.cpu().numpy()[use], ref["target_ind"][use])
+    assert (ref["target_ind"][use] - tind[use] > 256).sum() >= 10       # nearest points beyond the first chunk do occur
+    assert (ref["status"] == 2).sum() < B // 2
+    np.testing.assert_array_equal(eng.xref.cpu().numpy()[use], ref["xref"][use])
+
+
 def test_scripted_obstacles_vs_reference(pkg, routes):
     g = load_golden("obstacles_scripted.npz")
     eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
