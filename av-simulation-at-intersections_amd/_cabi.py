@@ -34,7 +34,7 @@ EXPORTS = (
     "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance", "jsim_mpc_run_ticks",
     "jsim_loop_set_geometry", "jsim_loop_set_obstacle_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
     "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_mpc_set_ego_config", "jsim_loop_obstacles",
-    "jsim_mpc_xref_deviation_goal",
+    "jsim_mpc_xref_deviation_goal", "jsim_loop_run_scenario",
 )
 
 _lib = None
@@ -93,6 +93,11 @@ def load() -> C.CDLL:
     lib.jsim_loop_obstacles.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     lib.jsim_mpc_run_ticks.restype = C.c_int
     lib.jsim_mpc_run_ticks.argtypes = [vp, i32, i32] + [vp] * 19 + [i32, vp, vp, i32, vp, vp]
+    lib.jsim_loop_run_scenario.restype = C.c_int
+    #                                       ctx B    ticks  x0..n_iter,di_ai,x0_spawn,target_spawn,age  max_age hist tick cap  n_resp
+    lib.jsim_loop_run_scenario.argtypes = ([vp, i32, i32] + [vp] * 19 + [i32, vp, vp, i32, vp] +
+                                           # traj_idx prev_len col_flag pre_status  window margin n_obs state param get  n_steps stream
+                                           [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp])
     lib.jsim_mpc_xref_deviation_goal.restype = C.c_int
     lib.jsim_mpc_xref_deviation_goal.argtypes = [vp, i32] + [vp] * 9
     if lib.jsim_abi_version() != ABI_VERSION:

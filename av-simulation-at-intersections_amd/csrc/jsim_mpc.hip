@@ -1064,21 +1064,28 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 #define JSIM_REG2_T_B 40
 #endif
 static bool has_reg_kernel(int T) { return T == 13 || T == 20 || T == JSIM_REG2_T_A || T == JSIM_REG2_T_B; }
-static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K)
+static bool has_fused_glue(int T) { return T == 13 || T == 20 || T == 30; }
+
+static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
 {
-    if (T == 13) hipLaunchKernelGGL(mpc_step_reg_kernel<13>, dim3(B), dim3(64), 0, s, P, K);
-    else if (T == 20) hipLaunchKernelGGL(mpc_step_reg_kernel<20>, dim3(B), dim3(64), 0, s, P, K);
+    static const PreK none = {};
+    if (Q) { // the loop glue inside the launch (one-wave kernels only)
+        if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        return;
+    }
+    if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false>), dim3(B), dim3(64), 0, s, P, K, none);
+    else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false>), dim3(B), dim3(64), 0, s, P, K, none);
 #ifdef JSIM_T30_TWO_WAVE
     else if (T == JSIM_REG2_T_A) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_A>, dim3(B), dim3(128), 0, s, P, K);
 #else
-    else if (T == 30) hipLaunchKernelGGL(mpc_step_reg_kernel<30>, dim3(B), dim3(64), 0, s, P, K);
+    else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
 #endif
 #if JSIM_REG2_T_B != JSIM_REG2_T_A
     else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_B>, dim3(B), dim3(128), 0, s, P, K);
 #endif
 }
-
-#include "loop_pre_tick.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // plant update for the per-vehicle loop (Simulation.step, main/lib/simulation.py:35-47) and the
@@ -1225,6 +1232,9 @@ struct jsim_ctx {
     double *h_cx, *h_cy, *h_cyaw;
     int have_geom;
     double cc0, cc1, col_radius;
+    double *d_get_all;     // [ticks][n_obs][6]  obstacle get() tuples of a fused scenario run
+    double2 *d_pred_all;   // [ticks][n_obs][n_steps][2]
+    size_t get_all_cap, pred_all_cap; // in elements
     double occ0, occ1, ocol_radius, oL; // the obstacles' circles / wheelbase (jsim_loop_set_obstacle_geometry); default: the ego's
     int have_ogeom;
     double2 *d_pcc;
@@ -1324,6 +1334,8 @@ extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     free_paths(ctx);
     if (ctx->d_pred_cc) (void)hipFree(ctx->d_pred_cc);
+    if (ctx->d_get_all) (void)hipFree(ctx->d_get_all);
+    if (ctx->d_pred_all) (void)hipFree(ctx->d_pred_all);
     delete ctx;
 }
 
@@ -1675,8 +1687,112 @@ extern "C" int jsim_loop_obstacles(jsim_ctx *ctx, int32_t n_obs, double *state, 
     if (n_obs < 0 || n_obs > JSIM_MAX_OBS) return fail(ctx, -22, "jsim_loop_obstacles: n_obs=%d (max %d)", n_obs, JSIM_MAX_OBS);
     if (n_obs == 0) return 0;
     if (!state || !param) return fail(ctx, -22, "jsim_loop_obstacles: null device pointer");
-    ObsStepP P = {n_obs, do_step ? 1 : 0, ctx->cfg.L, state, param, get};
+    ObsStepP P = {n_obs, do_step ? 1 : 0, ctx->have_ogeom ? ctx->oL : ctx->cfg.L, state, param, get};
     hipLaunchKernelGGL(obstacle_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// The whole scenario loop (main/scenarios/mpc_intersection.py:99-163) for n_ticks ticks.  With a one-wave register kernel and
+// one linearisation pass it is THREE launches: the scripted obstacles rolled forward n_ticks ticks (they do not depend on the
+// egos), their predictions for every tick, and the fused K-tick kernel with the loop glue inside each ego's tick loop.
+// Otherwise the same ticks as the separate calls a host loop would make.
+extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id,
+                                      int32_t *path_len, const double *speed, int64_t *target_ind, double *oa, double *od,
+                                      double *ox, double *oy, double *ov, double *oyaw, double *xref, uint32_t *active_mask,
+                                      int32_t *status, int32_t *n_iter, double *di_ai, const double *x0_spawn,
+                                      const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist, int32_t *tick,
+                                      int32_t hist_cap, uint64_t *n_respawn, int64_t *traj_idx, int32_t *prev_path_len,
+                                      int32_t *col_flag, int32_t *pre_status, int32_t frame_window, int32_t margin,
+                                      int32_t n_obs, double *obs_state, const double *obs_param, double *obs_get,
+                                      int32_t n_steps, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_loop_run_scenario: null ctx");
+    if (B < 0 || n_ticks < 0 || frame_window < 0 || frame_window > 32 || margin < 0)
+        return fail(ctx, -22, "jsim_loop_run_scenario: bad argument");
+    if (B == 0 || n_ticks == 0) return 0;
+    if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status || !di_ai || !x0_spawn || !target_spawn ||
+        !age || !traj_idx || !prev_path_len || !col_flag || !pre_status)
+        return fail(ctx, -22, "jsim_loop_run_scenario: a required device pointer is null");
+    if (n_obs < 0 || n_obs > JSIM_MAX_OBS || n_steps < 1 || n_steps > JSIM_MAX_PRED)
+        return fail(ctx, -22, "jsim_loop_run_scenario: n_obs=%d (max %d), n_steps=%d (max %d)", n_obs, JSIM_MAX_OBS, n_steps, JSIM_MAX_PRED);
+    if (n_obs > 0 && (!obs_state || !obs_param || !obs_get)) return fail(ctx, -22, "jsim_loop_run_scenario: null obstacle pointer");
+    if (hist && !tick) return fail(ctx, -22, "jsim_loop_run_scenario: hist needs a device tick counter");
+    if (!ctx->d_pxy || !ctx->d_pcc || !ctx->have_geom) return fail(ctx, -22, "jsim_loop_run_scenario: paths / geometry not set");
+    const jsim_cfg &c = ctx->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->use_reg_kernel || !has_fused_glue(c.T) || c.max_iter > 1 || ctx->cv_cut) {
+        // tick by tick, as ScenarioLoop.tick does
+        for (int k = 0; k < n_ticks; ++k) {
+            int rc = jsim_loop_obstacles(ctx, n_obs, obs_state, obs_param, obs_get, 0, stream);
+            if (rc) return rc;
+            ctx->pred_n_obs = n_obs; ctx->pred_n_steps = n_steps;
+            if (n_obs > 0) {
+                ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, obs_get, nullptr, ctx->d_pred_cc};
+                hipLaunchKernelGGL(obstacle_predict_kernel, dim3(1), dim3(64), 0, s, OP);
+            }
+            rc = jsim_loop_pre_tick(ctx, B, x0, path_id, traj_idx, prev_path_len, path_len, col_flag, nullptr, nullptr, pre_status,
+                                    frame_window, margin, nullptr, nullptr, stream);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(prev_path_len, path_len, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s));
+            rc = launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref, active_mask, status,
+                             n_iter, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+            if (rc) return rc;
+            rc = jsim_loop_advance(ctx, B, x0, oa, od, status, di_ai, target_ind, path_id, path_len, x0_spawn, target_spawn, age,
+                                   max_age, hist, tick, hist_cap, n_respawn, stream);
+            if (rc) return rc;
+            rc = jsim_loop_obstacles(ctx, n_obs, obs_state, obs_param, obs_get, 1, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    // obstacles: n_ticks ticks of get() tuples, then every tick's prediction
+    const size_t need_get = (size_t)n_ticks * (n_obs > 0 ? n_obs : 1) * 6;
+    const size_t need_pred = (size_t)n_ticks * (n_obs > 0 ? n_obs : 1) * n_steps * 2;
+    if (need_get > ctx->get_all_cap) {
+        if (ctx->d_get_all) (void)hipFree(ctx->d_get_all);
+        ctx->d_get_all = nullptr; ctx->get_all_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_get_all, sizeof(double) * need_get));
+        ctx->get_all_cap = need_get;
+    }
+    if (need_pred > ctx->pred_all_cap) {
+        if (ctx->d_pred_all) (void)hipFree(ctx->d_pred_all);
+        ctx->d_pred_all = nullptr; ctx->pred_all_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pred_all, sizeof(double2) * need_pred));
+        ctx->pred_all_cap = need_pred;
+    }
+    if (n_obs > 0) {
+        ObsStepP SP = {n_obs, 1, ctx->have_ogeom ? ctx->oL : c.L, obs_state, obs_param, nullptr};
+        hipLaunchKernelGGL(obstacle_rollout_kernel, dim3(1), dim3(64), 0, s, SP, n_ticks, ctx->d_get_all);
+        ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, ctx->d_get_all, nullptr, ctx->d_pred_all};
+        hipLaunchKernelGGL(obstacle_predict_kernel, dim3(n_ticks), dim3(64), 0, s, OP);
+        // the last get() tuples, as after n_ticks host ticks
+        HIP_TRY(ctx, hipMemcpyAsync(obs_get, ctx->d_get_all + (size_t)(n_ticks - 1) * n_obs * 6, sizeof(double) * n_obs * 6,
+                                    hipMemcpyDeviceToDevice, s));
+    }
+    ctx->pred_n_obs = n_obs; ctx->pred_n_steps = n_steps;
+    KP P;
+    fill_kp(ctx, B, P);
+    P.x0 = x0; P.path_id = path_id; P.path_len = path_len; P.speed = speed;
+    P.target_ind = (long long *)target_ind; P.oa = oa; P.od = od; P.ox = ox; P.oy = oy; P.ov = ov; P.oyaw = oyaw;
+    P.xref = xref; P.amask = active_mask; P.status = status; P.n_iter = n_iter;
+    P.dbg_clk = nullptr; P.dbg_max_gi = ctx->dbg_max_gi;
+    TickP K;
+    memset(&K, 0, sizeof(K));
+    K.n_ticks = n_ticks; K.advance = 1; K.max_age = max_age > 0 ? max_age : 0x7fffffff; K.hist_cap = hist_cap;
+    K.max_decel = c.max_decel; K.goal_dis = c.goal_dis; K.stop_speed = c.stop_speed;
+    K.x0w = x0; K.di_ai = di_ai; K.x0_spawn = x0_spawn; K.target_spawn = (const long long *)target_spawn; K.age = age;
+    K.hist = hist; K.tick = tick; K.n_respawn = (unsigned long long *)n_respawn;
+    PreK Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.pre.B = B; Q.pre.n_obs = n_obs; Q.pre.n_steps = n_steps; Q.pre.frame_window = frame_window; Q.pre.margin = margin;
+    Q.pre.dt = c.dt; Q.pre.max_accel = c.max_accel; Q.pre.max_speed = c.max_speed; Q.pre.thr = ctx->col_radius + ctx->ocol_radius;
+    Q.pre.pxy = ctx->d_pxy; Q.pre.pcc = ctx->d_pcc; Q.pre.poff = ctx->d_poff;
+    Q.pred_cc_all = ctx->d_pred_all; Q.traj_idx = (long long *)traj_idx; Q.prev_len = prev_path_len; Q.path_len_out = path_len;
+    Q.col_flag = col_flag; Q.pre_status = pre_status;
+    launch_reg(c.T, B, s, P, K, &Q);
+    if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -158,6 +158,21 @@ int jsim_mpc_set_ego_config(jsim_ctx *ctx, const double *cfg);
  *   exactly what jsim_mpc_step takes.  prev_path_len [B]: previous tick's path_len, -1 before the first tick.
  *   status: 0 ok, 2 nearest-index anomaly, 4 resampled path longer than the kernel's 320-point table. */
 int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius);
+/* n_ticks ticks of the WHOLE scenario loop (main/scenarios/mpc_intersection.py:99-163) for B egos and n_obs scripted obstacle
+ * vehicles: obstacle get() -> prediction -> progress index / resample / collision / cut-off (jsim_loop_pre_tick) -> MPC.step ->
+ * plant, history, goal (jsim_loop_advance) -> obstacle step().  Arguments as in jsim_mpc_run_ticks, jsim_loop_pre_tick
+ * (traj_idx, prev_path_len in/out; path_len, col_flag, pre_status out) and jsim_loop_obstacles (obs_state in/out, obs_param,
+ * obs_get [n_obs][6] out).  With a one-wave register kernel (T = 13, 20, 30), MAX_ITER = 1 and path truncation (no
+ * jsim_mpc_set_speed_cutoff buffer) it is three launches: obstacles rolled forward n_ticks ticks, their predictions for
+ * every tick, and ONE fused launch in which every ego's wave runs its own glue + solve + plant n_ticks times; otherwise the
+ * same ticks as separate launches.  Identical results either way. */
+int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id, int32_t *path_len,
+                           const double *speed, int64_t *target_ind, double *oa, double *od, double *ox, double *oy, double *ov,
+                           double *oyaw, double *xref, uint32_t *active_mask, int32_t *status, int32_t *n_iter, double *di_ai,
+                           const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist,
+                           int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, int64_t *traj_idx, int32_t *prev_path_len,
+                           int32_t *col_flag, int32_t *pre_status, int32_t frame_window, int32_t margin, int32_t n_obs,
+                           double *obs_state, const double *obs_param, double *obs_get, int32_t n_steps, void *stream);
 /* Obstacles of another shape than the ego (main/scenarios/overtaking_cyclist_bidirectional_road.py:122-133: the cyclist's
  * BicycleRealDimensions): their two circles and wheelbase -- used by the prediction (MovingObstaclesPrediction(...,
  * car_dimensions=bicycle_dimensions)) and by the collision rows of check_collision_moving_bicycle,

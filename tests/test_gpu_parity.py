@@ -535,6 +535,37 @@ def test_nearest_index_on_self_approaching_paths(pkg, oracle, T):
     np.testing.assert_array_equal(eng.xref.cpu().numpy()[use], ref["xref"][use])
 
 
+@pytest.mark.parametrize("T", (13, 20, 30, 40))
+def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T):
+    """The whole scenario loop -- obstacles, prediction, progress index / resample / collision / cut-off, MPC step, plant,
+    goal -- for K ticks in one call (jsim_loop_run_scenario: three launches for T = 13 / 20 / 30, the glue inside each ego's
+    tick loop; tick-by-tick launches for T = 40) against the same ticks driven from the host: every buffer bit-identical."""
+    B, K1, K2 = 48, 7, 9
+    specs = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None), dict(direction=-1, turning=True, speed=20 / 3.6, offset=1.0),
+             dict(kind="roundabout", direction=1, turning=True, speed=15 / 3.6, offset=2.0)]
+    outs = []
+    for fused in (False, True):
+        batch = pkg.synth.make_ego_batch(routes, B, T, seed=17)
+        eng = _engine(pkg, routes, batch, T)
+        x0 = torch.from_numpy(batch.x0).to(eng.device)
+        sc = pkg.ScenarioLoop(eng, x0, specs, hist_cap=K1 + K2, max_age=0)
+        if fused:
+            sc.run(K1); sc.run(K2)
+        else:
+            for _ in range(K1 + K2):
+                sc.tick()
+        torch.cuda.synchronize()
+        outs.append(dict(x0=sc.loop.x0.clone(), path_len=eng.path_len.clone(), traj_idx=sc.pre.traj_idx.clone(),
+                         prev_len=sc.pre.prev_len.clone(), col=sc.pre.col_flag.clone(), pst=sc.pre.status.clone(),
+                         oa=eng.oa.clone(), od=eng.od.clone(), tind=eng.target_ind.clone(), status=eng.status.clone(),
+                         hist=sc.loop.hist.clone(), obs=sc.obst.state.clone(), get=sc.obst.get_buf.clone(), di_ai=eng.di_ai.clone(),
+                         age=sc.loop.age.clone(), tick=sc.loop.tick_counter.clone()))
+    a, b = outs
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int((a["col"] != 0).sum()) > 0 and int((a["path_len"].cpu() < torch.from_numpy(batch.path_len)).sum()) > 0
+
+
 def test_scripted_obstacles_vs_reference(pkg, routes):
     g = load_golden("obstacles_scripted.npz")
     eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)

@@ -2,7 +2,8 @@
 """Diagnostic: the WHOLE per-vehicle loop of main/scenarios/mpc_intersection.py:99-163 on the device for a batch -- obstacle
 get() -> prediction -> progress index / resample / collision / cut-off -> MPC.step -> plant, goal -> obstacle step() -- at
 config 3's shape (default 4096 egos, T = 30, four scripted obstacle vehicles, FRAME_WINDOW = 10), one set of launches per tick.
-Prints ticks/s, MPC steps/s and how the tick divides between the loop glue (f1) and the MPC step.
+Prints ticks/s, MPC steps/s, how the tick divides between the loop glue (f1) and the MPC step, and the same loop fused
+into one call (jsim_loop_run_scenario).
 
     python tools/bench_scenario_loop.py [B=4096] [T=30] [ticks=60]
 """
@@ -58,7 +59,11 @@ def glue():
 
 ms_glue = timed(glue, K)
 ms_mpc = timed(sc.loop.tick, K)
+# the same loop in ONE call: obstacles rolled forward K ticks, their predictions for every tick, one fused launch
+sc.run(K)
+ms_fused = timed(lambda: sc.run(K), 3) / K
 print(f"{B} egos, T = {T}, {len(specs)} obstacle vehicles, FRAME_WINDOW = {sc.pre.frame_window}, {sc.pre.n_steps} predicted frames:")
+print(f"  fused: {K} ticks per call      {ms_fused:8.3f} ms per tick -> {B / ms_fused * 1e3 / 1e6:.2f} M MPC steps/s (glue inside each ego's tick loop)")
 print(f"  whole loop tick            {ms_tick:8.3f} ms  -> {B / ms_tick * 1e3 / 1e6:.2f} M MPC steps/s with the loop glue on the device")
 print(f"  loop glue alone (f1)       {ms_glue:8.3f} ms  ({100 * ms_glue / ms_tick:.0f} % of the tick; obstacle get + prediction + pre-tick kernel)")
 print(f"  MPC step + advance alone   {ms_mpc:8.3f} ms")
