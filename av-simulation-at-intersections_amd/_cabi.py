@@ -96,8 +96,8 @@ def load() -> C.CDLL:
     lib.jsim_loop_run_scenario.restype = C.c_int
     #                                       ctx B    ticks  x0..n_iter,di_ai,x0_spawn,target_spawn,age  max_age hist tick cap  n_resp
     lib.jsim_loop_run_scenario.argtypes = ([vp, i32, i32] + [vp] * 19 + [i32, vp, vp, i32, vp] +
-                                           # traj_idx prev_len col_flag pre_status  window margin n_obs state param get  n_steps stream
-                                           [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp])
+                                           # traj_idx prev_len col_flag pre_status  window margin n_obs state param get  n_steps speed_cutoff stream
+                                           [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, vp])
     lib.jsim_mpc_xref_deviation_goal.restype = C.c_int
     lib.jsim_mpc_xref_deviation_goal.argtypes = [vp, i32] + [vp] * 9
     if lib.jsim_abi_version() != ABI_VERSION:

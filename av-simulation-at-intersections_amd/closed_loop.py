@@ -232,14 +232,10 @@ class ScenarioLoop:
 
     def run(self, n_ticks: int):
         """n_ticks ticks in one call (jsim_loop_run_scenario).  With a one-wave register kernel (T = 13, 20, 30), MAX_ITER = 1
-        and mode "truncate": three launches -- the scripted obstacles rolled forward n_ticks ticks, their predictions for every
+        three launches -- the scripted obstacles rolled forward n_ticks ticks, their predictions for every
         tick, and one fused launch in which each ego's wavefront does glue + solve + plant n_ticks times.  Same results as
         n_ticks x tick()."""
         loop, pre, ob, eng = self.loop, self.pre, self.obst, self.loop.eng
-        if pre.mode != "truncate":
-            for _ in range(int(n_ticks)):
-                self.tick()
-            return
         eng._check_x0(loop.x0)
         _cabi.check(eng.lib.jsim_loop_run_scenario(
             eng._ctx, eng.B, int(n_ticks), _ptr(loop.x0), _ptr(eng.path_id), _ptr(eng.path_len), _ptr(eng.speed),
@@ -248,6 +244,7 @@ class ScenarioLoop:
             _ptr(loop.x0_spawn), _ptr(loop.target_spawn), _ptr(loop.age), loop.max_age, _ptr(loop.hist),
             _ptr(loop.tick_counter), loop.hist_cap, _ptr(loop.n_respawn), _ptr(pre.traj_idx), _ptr(pre.prev_len),
             _ptr(pre.col_flag), _ptr(pre.status), pre.frame_window, pre.margin, ob.n, _ptr(ob.state) if ob.n else None,
-            _ptr(ob.param) if ob.n else None, _ptr(ob.get_buf) if ob.n else None, pre.n_steps, eng._stream()), eng._ctx,
+            _ptr(ob.param) if ob.n else None, _ptr(ob.get_buf) if ob.n else None, pre.n_steps,
+            1 if pre.mode == "speed_cutoff" else 0, eng._stream()), eng._ctx,
             "jsim_loop_run_scenario")
         pre.n_obs = ob.n

@@ -1705,7 +1705,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
                                       int32_t hist_cap, uint64_t *n_respawn, int64_t *traj_idx, int32_t *prev_path_len,
                                       int32_t *col_flag, int32_t *pre_status, int32_t frame_window, int32_t margin,
                                       int32_t n_obs, double *obs_state, const double *obs_param, double *obs_get,
-                                      int32_t n_steps, void *stream)
+                                      int32_t n_steps, int32_t speed_cutoff, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_run_scenario: null ctx");
     if (B < 0 || n_ticks < 0 || frame_window < 0 || frame_window > 32 || margin < 0)
@@ -1722,7 +1722,10 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     const jsim_cfg &c = ctx->cfg;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->use_reg_kernel || !has_fused_glue(c.T) || c.max_iter > 1 || ctx->cv_cut) {
+    if (speed_cutoff && !ctx->cv_cut)
+        return fail(ctx, -22, "jsim_loop_run_scenario: the speed-cut-off glue needs jsim_mpc_set_speed_cutoff first");
+    int32_t *const glue_out = speed_cutoff ? const_cast<int32_t *>(ctx->cv_cut) : path_len; // where the cut-off index goes
+    if (!ctx->use_reg_kernel || !has_fused_glue(c.T) || c.max_iter > 1 || (ctx->cv_cut && !speed_cutoff)) {
         // tick by tick, as ScenarioLoop.tick does
         for (int k = 0; k < n_ticks; ++k) {
             int rc = jsim_loop_obstacles(ctx, n_obs, obs_state, obs_param, obs_get, 0, stream);
@@ -1732,9 +1735,10 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
                 ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, obs_get, nullptr, ctx->d_pred_cc};
                 hipLaunchKernelGGL(obstacle_predict_kernel, dim3(1), dim3(64), 0, s, OP);
             }
-            rc = jsim_loop_pre_tick(ctx, B, x0, path_id, traj_idx, prev_path_len, path_len, col_flag, nullptr, nullptr, pre_status,
+            rc = jsim_loop_pre_tick(ctx, B, x0, path_id, traj_idx, prev_path_len, glue_out, col_flag, nullptr, nullptr, pre_status,
                                     frame_window, margin, nullptr, nullptr, stream);
             if (rc) return rc;
+            // the previous tmp_trajectory: the truncated path, or always the full one (mpc_intersection_new_ref.py:131)
             HIP_TRY(ctx, hipMemcpyAsync(prev_path_len, path_len, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s));
             rc = launch_step(ctx, B, x0, path_id, path_len, speed, target_ind, oa, od, ox, oy, ov, oyaw, xref, active_mask, status,
                              n_iter, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
@@ -1791,6 +1795,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     Q.pre.pxy = ctx->d_pxy; Q.pre.pcc = ctx->d_pcc; Q.pre.poff = ctx->d_poff;
     Q.pred_cc_all = ctx->d_pred_all; Q.traj_idx = (long long *)traj_idx; Q.prev_len = prev_path_len; Q.path_len_out = path_len;
     Q.col_flag = col_flag; Q.pre_status = pre_status;
+    Q.speed_cutoff = speed_cutoff ? 1 : 0; Q.cut_io = glue_out;
     launch_reg(c.T, B, s, P, K, &Q);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());

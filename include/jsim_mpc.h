@@ -162,8 +162,9 @@ int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, doubl
  * vehicles: obstacle get() -> prediction -> progress index / resample / collision / cut-off (jsim_loop_pre_tick) -> MPC.step ->
  * plant, history, goal (jsim_loop_advance) -> obstacle step().  Arguments as in jsim_mpc_run_ticks, jsim_loop_pre_tick
  * (traj_idx, prev_path_len in/out; path_len, col_flag, pre_status out) and jsim_loop_obstacles (obs_state in/out, obs_param,
- * obs_get [n_obs][6] out).  With a one-wave register kernel (T = 13, 20, 30), MAX_ITER = 1 and path truncation (no
- * jsim_mpc_set_speed_cutoff buffer) it is three launches: obstacles rolled forward n_ticks ticks, their predictions for
+ * obs_get [n_obs][6] out).  speed_cutoff = 1: the glue of main/scenarios/mpc_intersection_new_ref.py:122-139 -- the path
+ * stays whole (path_len must hold the full lengths) and the cut-off index goes to the buffer registered with
+ * jsim_mpc_set_speed_cutoff.  With a one-wave register kernel (T = 13, 20, 30) and MAX_ITER = 1 it is three launches: obstacles rolled forward n_ticks ticks, their predictions for
  * every tick, and ONE fused launch in which every ego's wave runs its own glue + solve + plant n_ticks times; otherwise the
  * same ticks as separate launches.  Identical results either way. */
 int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id, int32_t *path_len,
@@ -172,7 +173,8 @@ int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0
                            const double *x0_spawn, const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist,
                            int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, int64_t *traj_idx, int32_t *prev_path_len,
                            int32_t *col_flag, int32_t *pre_status, int32_t frame_window, int32_t margin, int32_t n_obs,
-                           double *obs_state, const double *obs_param, double *obs_get, int32_t n_steps, void *stream);
+                           double *obs_state, const double *obs_param, double *obs_get, int32_t n_steps, int32_t speed_cutoff,
+                           void *stream);
 /* Obstacles of another shape than the ego (main/scenarios/overtaking_cyclist_bidirectional_road.py:122-133: the cyclist's
  * BicycleRealDimensions): their two circles and wheelbase -- used by the prediction (MovingObstaclesPrediction(...,
  * car_dimensions=bicycle_dimensions)) and by the collision rows of check_collision_moving_bicycle,

@@ -241,6 +241,35 @@ def test_new_ref_loop_glue_speed_cutoff_mode(pkg, routes):
         pkg.PreTick(pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, smooth=False), mode="speed_cutoff")
 
 
+@pytest.mark.gpu
+def test_fused_scenario_loop_speed_cutoff_glue(pkg, routes):
+    """The new_ref glue (cut-off -> the controller's speed reference, path never truncated) through ScenarioLoop.run: one fused
+    call against the same ticks driven from the host, every buffer bit-identical."""
+    T, B, K = 13, 40, 12
+    m = pkg.mpc_with_speed
+    cvs = [np.full(len(r), m.MAX_SPEED) for r in routes]
+    specs = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None), dict(direction=-1, turning=True, speed=20 / 3.6, offset=1.0)]
+    outs = []
+    for fused in (False, True):
+        batch = pkg.synth.make_ego_batch(routes, B, T, seed=19, truncate=False, near_end_frac=0.0)
+        eng = pkg.BatchedMPC(routes, batch.path_id, dl=pkg.synth.DL, T=T, speed=batch.speed, smooth=False, config=m.config, cv=cvs)
+        eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+        sc = pkg.ScenarioLoop(eng, torch.from_numpy(batch.x0).cuda(), specs, hist_cap=K, frame_window=20, mode="speed_cutoff")
+        if fused:
+            sc.run(K)
+        else:
+            for _ in range(K):
+                sc.tick()
+        torch.cuda.synchronize()
+        outs.append(dict(x0=sc.loop.x0.clone(), cut=sc.pre.cut.clone(), path_len=eng.path_len.clone(), traj_idx=sc.pre.traj_idx.clone(),
+                         prev=sc.pre.prev_len.clone(), col=sc.pre.col_flag.clone(), oa=eng.oa.clone(), od=eng.od.clone(),
+                         hist=sc.loop.hist.clone(), xref=eng.xref.clone(), obs=sc.obst.state.clone()))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert torch.equal(outs[1]["path_len"], torch.from_numpy(batch.path_len).cuda())          # the path stays whole
+    assert int((outs[1]["cut"] < outs[1]["path_len"]).sum()) > 0                                # somebody got a speed cut-off
+
+
 # ------------------------------------------------------------------------------------------------
 # lib.mpc_jerk: the acceleration-state variant (NX = 5, free acc_0: 2T + 1 decision variables)
 # ------------------------------------------------------------------------------------------------
