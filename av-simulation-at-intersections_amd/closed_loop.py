@@ -228,6 +228,9 @@ class ScenarioLoop:
         self.pre.predict(g)
         self.pre.run(self.loop.x0)
         self.loop.tick()
+        resp = self.loop.age == 0                    # respawned this tick: the glue starts over like for a new run
+        self.pre.traj_idx.masked_fill_(resp, 0)
+        self.pre.prev_len.masked_fill_(resp, -1)
         self.obst.get(step=True)
 
     def run(self, n_ticks: int):

@@ -1693,6 +1693,13 @@ extern "C" int jsim_loop_obstacles(jsim_ctx *ctx, int32_t n_obs, double *state, 
     return 0;
 }
 
+// an ego that was just respawned (age == 0 after the advance) starts its run like a new one: progress index 0, no previous path
+__global__ __launch_bounds__(256) void glue_reset_kernel(int B, const int *age, long long *traj_idx, int *prev_len)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && age[b] == 0) { traj_idx[b] = 0; prev_len[b] = -1; }
+}
+
 // The whole scenario loop (main/scenarios/mpc_intersection.py:99-163) for n_ticks ticks.  With a one-wave register kernel and
 // one linearisation pass it is THREE launches: the scripted obstacles rolled forward n_ticks ticks (they do not depend on the
 // egos), their predictions for every tick, and the fused K-tick kernel with the loop glue inside each ego's tick loop.
@@ -1746,6 +1753,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
             rc = jsim_loop_advance(ctx, B, x0, oa, od, status, di_ai, target_ind, path_id, path_len, x0_spawn, target_spawn, age,
                                    max_age, hist, tick, hist_cap, n_respawn, stream);
             if (rc) return rc;
+            hipLaunchKernelGGL(glue_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, age, (long long *)traj_idx, prev_path_len);
             rc = jsim_loop_obstacles(ctx, n_obs, obs_state, obs_param, obs_get, 1, stream);
             if (rc) return rc;
         }

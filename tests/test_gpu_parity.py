@@ -535,8 +535,8 @@ def test_nearest_index_on_self_approaching_paths(pkg, oracle, T):
     np.testing.assert_array_equal(eng.xref.cpu().numpy()[use], ref["xref"][use])
 
 
-@pytest.mark.parametrize("T", (13, 20, 30, 40))
-def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T):
+@pytest.mark.parametrize("T,max_age", ((13, 0), (20, 0), (30, 0), (40, 0), (20, 5), (40, 5)))
+def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T, max_age):
     """The whole scenario loop -- obstacles, prediction, progress index / resample / collision / cut-off, MPC step, plant,
     goal -- for K ticks in one call (jsim_loop_run_scenario: three launches for T = 13 / 20 / 30, the glue inside each ego's
     tick loop; tick-by-tick launches for T = 40) against the same ticks driven from the host: every buffer bit-identical."""
@@ -548,7 +548,7 @@ def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T):
         batch = pkg.synth.make_ego_batch(routes, B, T, seed=17)
         eng = _engine(pkg, routes, batch, T)
         x0 = torch.from_numpy(batch.x0).to(eng.device)
-        sc = pkg.ScenarioLoop(eng, x0, specs, hist_cap=K1 + K2, max_age=0)
+        sc = pkg.ScenarioLoop(eng, x0, specs, hist_cap=K1 + K2, max_age=max_age)   # max_age = 5: every ego respawns, twice
         if fused:
             sc.run(K1); sc.run(K2)
         else:
@@ -564,6 +564,7 @@ def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert int((a["col"] != 0).sum()) > 0 and int((a["path_len"].cpu() < torch.from_numpy(batch.path_len)).sum()) > 0
+    assert int((a["pst"] != 0).sum()) == 0     # the glue never lost its footing (respawned egos restart their progress index)
 
 
 def test_scripted_obstacles_vs_reference(pkg, routes):
@@ -597,10 +598,13 @@ def test_scenario_loop_on_device_config1(pkg, routes):
         st = sc.loop.x0[0].cpu().numpy()
         np.testing.assert_allclose(st, [x, y, v, yaw], rtol=0, atol=1e-6)
         sc.tick()
-        assert int(sc.pre.traj_idx.item()) == int(row[6]) and int(eng.path_len.item()) == int(row[7])
+        assert int(eng.path_len.item()) == int(row[7])
         assert int(eng.status.item()) == int(row[11])
-        if k < K - 1:     # the last recorded tick ends at the goal: the device loop respawns the ego (target_ind -> 0)
+        if k < K - 1:     # the last recorded tick ends at the goal: the device loop respawns the ego (target_ind, progress index -> 0)
             assert int(eng.target_ind.item()) == int(row[10]) and int(sc.loop.n_respawn.item()) == 0
+            assert int(sc.pre.traj_idx.item()) == int(row[6])
+        else:
+            assert int(sc.pre.traj_idx.item()) == 0 and int(sc.pre.prev_len.item()) == -1
         n_cut += int(sc.pre.col_flag.item())
     hist = sc.loop.hist[:K, 0].cpu().numpy()
     np.testing.assert_allclose(hist[:, 0], g["ticks"][:, 12], rtol=0, atol=1e-6)   # delta
