@@ -1579,6 +1579,16 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     return 0;
 }
 
+// the largest double x with sqrt(x) <= thr (IEEE sqrt is correctly rounded and monotone): comparing a squared distance with it
+// decides exactly what comparing its square root with thr decides
+static double jsim_sqrt_threshold(double thr)
+{
+    double x = thr * thr;
+    while (std::sqrt(x) > thr) x = std::nextafter(x, 0.0);
+    while (std::sqrt(std::nextafter(x, INFINITY)) <= thr) x = std::nextafter(x, INFINITY);
+    return x;
+}
+
 extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_set_geometry: null ctx");
@@ -1631,6 +1641,7 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
     memset(&P, 0, sizeof(P));
     P.B = B; P.n_obs = ctx->pred_n_obs; P.n_steps = ctx->pred_n_steps; P.frame_window = frame_window; P.margin = margin;
     P.dt = c.dt; P.max_accel = c.max_accel; P.max_speed = c.max_speed; P.thr = ctx->col_radius + ctx->ocol_radius; // min_distance: 2 * radius, or car radius + bicycle radius
+    P.thr_sq = jsim_sqrt_threshold(P.thr);
     P.pxy = ctx->d_pxy; P.pcc = ctx->d_pcc; P.poff = ctx->d_poff; P.pred_cc = ctx->d_pred_cc;
     P.x0 = x0; P.path_id = path_id; P.traj_idx = (long long *)traj_idx; P.prev_path_len = prev_path_len; P.path_len = path_len;
     P.col_flag = col_flag; P.col_xy = col_xy; P.first_idx = first_idx; P.status = status;
@@ -1800,6 +1811,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     memset(&Q, 0, sizeof(Q));
     Q.pre.B = B; Q.pre.n_obs = n_obs; Q.pre.n_steps = n_steps; Q.pre.frame_window = frame_window; Q.pre.margin = margin;
     Q.pre.dt = c.dt; Q.pre.max_accel = c.max_accel; Q.pre.max_speed = c.max_speed; Q.pre.thr = ctx->col_radius + ctx->ocol_radius;
+    Q.pre.thr_sq = jsim_sqrt_threshold(Q.pre.thr);
     Q.pre.pxy = ctx->d_pxy; Q.pre.pcc = ctx->d_pcc; Q.pre.poff = ctx->d_poff;
     Q.pred_cc_all = ctx->d_pred_all; Q.traj_idx = (long long *)traj_idx; Q.prev_len = prev_path_len; Q.path_len_out = path_len;
     Q.col_flag = col_flag; Q.pre_status = pre_status;

@@ -25,13 +25,19 @@ S = pkg.synth
 routes = S.make_route_table()
 for r in routes:
     S.smooth_yaw_inplace(r[:, 2])
-batch = S.make_ego_batch(routes, B, T, seed=1)
-eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smooth=False)
-eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
-x0 = torch.from_numpy(batch.x0).cuda()
 specs = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None), dict(direction=-1, turning=True, speed=20 / 3.6, offset=6.0),
          dict(direction=1, turning=True, speed=15 / 3.6, offset=12.0), dict(direction=-1, turning=False, speed=25 / 3.6, offset=3.0)]
-sc = pkg.ScenarioLoop(eng, x0, specs, max_age=400)
+
+
+def make():
+    batch = S.make_ego_batch(routes, B, T, seed=1)
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smooth=False)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    return batch, eng, pkg.ScenarioLoop(eng, torch.from_numpy(batch.x0).cuda(), specs, max_age=400)
+
+
+batch, eng, sc = make()          # driven tick by tick from the host
+_, eng_f, sc_f = make()          # the same simulation, K ticks per call
 
 
 def timed(fn, n):
@@ -47,7 +53,10 @@ def timed(fn, n):
 
 for _ in range(10):
     sc.tick()
-ms_tick = timed(sc.tick, K)
+sc_f.run(10)
+ms_tick = timed(sc.tick, K)                      # ticks 10 .. 10 + K of the simulation
+ms_fused = timed(lambda: sc_f.run(K), 1) / K     # the same ticks in one call
+assert torch.equal(sc.loop.x0, sc_f.loop.x0) and torch.equal(eng.path_len, eng_f.path_len)
 cut = int((eng.path_len.cpu().numpy() < batch.path_len).sum())
 
 
@@ -59,9 +68,6 @@ def glue():
 
 ms_glue = timed(glue, K)
 ms_mpc = timed(sc.loop.tick, K)
-# the same loop in ONE call: obstacles rolled forward K ticks, their predictions for every tick, one fused launch
-sc.run(K)
-ms_fused = timed(lambda: sc.run(K), 3) / K
 print(f"{B} egos, T = {T}, {len(specs)} obstacle vehicles, FRAME_WINDOW = {sc.pre.frame_window}, {sc.pre.n_steps} predicted frames:")
 print(f"  fused: {K} ticks per call      {ms_fused:8.3f} ms per tick -> {B / ms_fused * 1e3 / 1e6:.2f} M MPC steps/s (glue inside each ego's tick loop)")
 print(f"  whole loop tick            {ms_tick:8.3f} ms  -> {B / ms_tick * 1e3 / 1e6:.2f} M MPC steps/s with the loop glue on the device")
