@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 #define JSIM_REG2_T_B 40
 #endif
 static bool has_reg_kernel(int T) { return T == 13 || T == 20 || T == JSIM_REG2_T_A || T == JSIM_REG2_T_B; }
-static bool has_fused_glue(int T) { return T == 13 || T == 20 || T == 30; }
+static bool has_fused_glue(int T) { return has_reg_kernel(T); }
 
 static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
 {
@@ -1073,17 +1073,18 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
         if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_B, true>), dim3(B), dim3(128), 0, s, P, K, *Q);
         return;
     }
     if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false>), dim3(B), dim3(64), 0, s, P, K, none);
     else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false>), dim3(B), dim3(64), 0, s, P, K, none);
 #ifdef JSIM_T30_TWO_WAVE
-    else if (T == JSIM_REG2_T_A) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_A>, dim3(B), dim3(128), 0, s, P, K);
+    else if (T == JSIM_REG2_T_A) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_A, false>), dim3(B), dim3(128), 0, s, P, K, none);
 #else
     else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
 #endif
 #if JSIM_REG2_T_B != JSIM_REG2_T_A
-    else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL(mpc_step_reg2_kernel<JSIM_REG2_T_B>, dim3(B), dim3(128), 0, s, P, K);
+    else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_B, false>), dim3(B), dim3(128), 0, s, P, K, none);
 #endif
 }
 

@@ -202,7 +202,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": (f"mpc_step_reg_kernel<{T}, false>" if T in (13, 20, 30) else
-                                    f"mpc_step_reg2_kernel<{T}>" if T == 40 else "mpc_step_kernel"), "kernel_ms": kern_ms,
+                                    f"mpc_step_reg2_kernel<{T}, false>" if T == 40 else "mpc_step_kernel"), "kernel_ms": kern_ms,
                          "ticks_per_launch": ticks_per_launch,
                          "algorithmic_flops_per_launch": flops,
                          "note": ("fp64 vector/matrix peak; latency-bound: " +

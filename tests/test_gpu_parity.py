@@ -535,11 +535,12 @@ def test_nearest_index_on_self_approaching_paths(pkg, oracle, T):
     np.testing.assert_array_equal(eng.xref.cpu().numpy()[use], ref["xref"][use])
 
 
-@pytest.mark.parametrize("T,max_age", ((13, 0), (20, 0), (30, 0), (40, 0), (20, 5), (40, 5)))
+@pytest.mark.parametrize("T,max_age", ((13, 0), (20, 0), (30, 0), (40, 0), (25, 0), (20, 5), (40, 5), (25, 5)))
 def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T, max_age):
     """The whole scenario loop -- obstacles, prediction, progress index / resample / collision / cut-off, MPC step, plant,
-    goal -- for K ticks in one call (jsim_loop_run_scenario: three launches for T = 13 / 20 / 30, the glue inside each ego's
-    tick loop; tick-by-tick launches for T = 40) against the same ticks driven from the host: every buffer bit-identical."""
+    goal -- for K ticks in one call (jsim_loop_run_scenario: three launches for T = 13 / 20 / 30 / 40, the glue inside each ego's
+    tick loop; tick-by-tick launches inside the same call for T = 25, which has no register kernel) against the same ticks
+    driven from the host: every buffer bit-identical."""
     B, K1, K2 = 48, 7, 9
     specs = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None), dict(direction=-1, turning=True, speed=20 / 3.6, offset=1.0),
              dict(kind="roundabout", direction=1, turning=True, speed=15 / 3.6, offset=2.0)]
