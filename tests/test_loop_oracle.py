@@ -108,3 +108,24 @@ def test_bicycle_obstacle_glue_vs_reference(LO, routes):
                                            margin_factor=2)
         assert st == 0 and i2 == idx and plen == int(g["cutoff"][k])
     assert 40 <= n_col <= 110
+
+
+def test_squared_distance_threshold_is_exactly_the_sqrt_comparison():
+    """The collision rows on the device compare dx*dx + dy*dy with the largest double whose correctly rounded square root is
+    <= min_distance (csrc/jsim_mpc.hip: jsim_sqrt_threshold) instead of comparing the square root with min_distance as
+    numpy does (collision_avoidance.py:99).  Same decision for every double: checked here on the doubles around thr^2."""
+    for thr in (2 * 2.0 / np.sqrt(2.0), 2.0 / np.sqrt(2.0) + 0.45 / np.sqrt(2.0), 0.001, 1.0, 3.0):
+        x = thr * thr
+        while np.sqrt(x) > thr:
+            x = np.nextafter(x, 0.0)
+        while np.sqrt(np.nextafter(x, np.inf)) <= thr:
+            x = np.nextafter(x, np.inf)
+        d2 = x
+        for _ in range(2000):                       # 2000 doubles below, then 2000 above the threshold
+            d2 = np.nextafter(d2, 0.0)
+        for _ in range(4000):
+            assert (np.sqrt(d2) <= thr) == (d2 <= x)
+            d2 = np.nextafter(d2, np.inf)
+        rng = np.random.default_rng(1)
+        far = rng.uniform(0.0, 4.0 * x, 20000)
+        assert np.array_equal(np.sqrt(far) <= thr, far <= x)
