@@ -1235,6 +1235,8 @@ struct jsim_ctx {
     double cc0, cc1, col_radius;
     double *d_get_all;     // [ticks][n_obs][6]  obstacle get() tuples of a fused scenario run
     double2 *d_pred_all;   // [ticks][n_obs][n_steps][2]
+    double4 *d_bc_all;     // [ticks][n_obs] bounding circles of the predictions
+    double4 *d_pred_bc;    // [JSIM_MAX_OBS] of the current single-tick prediction
     size_t get_all_cap, pred_all_cap; // in elements
     double occ0, occ1, ocol_radius, oL; // the obstacles' circles / wheelbase (jsim_loop_set_obstacle_geometry); default: the ego's
     int have_ogeom;
@@ -1337,6 +1339,8 @@ extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
     if (ctx->d_pred_cc) (void)hipFree(ctx->d_pred_cc);
     if (ctx->d_get_all) (void)hipFree(ctx->d_get_all);
     if (ctx->d_pred_all) (void)hipFree(ctx->d_pred_all);
+    if (ctx->d_bc_all) (void)hipFree(ctx->d_bc_all);
+    if (ctx->d_pred_bc) (void)hipFree(ctx->d_pred_bc);
     delete ctx;
 }
 
@@ -1598,6 +1602,7 @@ extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_
     ctx->cc0 = cc_front; ctx->cc1 = cc_rear; ctx->col_radius = radius; ctx->have_geom = 1;
     if (!ctx->have_ogeom) { ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = ctx->cfg.L; }
     if (!ctx->d_pred_cc) HIP_TRY(ctx, hipMalloc(&ctx->d_pred_cc, sizeof(double2) * JSIM_MAX_OBS * JSIM_MAX_PRED * 2));
+    if (!ctx->d_pred_bc) HIP_TRY(ctx, hipMalloc(&ctx->d_pred_bc, sizeof(double4) * JSIM_MAX_OBS));
     return upload_circle_centres(ctx);
 }
 
@@ -1619,7 +1624,7 @@ extern "C" int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const d
     ctx->pred_n_obs = n_obs; ctx->pred_n_steps = n_steps;
     if (n_obs == 0) return 0;
     if (!obst || !pred) return fail(ctx, -22, "jsim_loop_predict_obstacles: null device pointer");
-    ObsP P = {n_obs, n_steps, ctx->cfg.dt, ctx->oL, ctx->occ0, ctx->occ1, obst, pred, ctx->d_pred_cc};
+    ObsP P = {n_obs, n_steps, ctx->cfg.dt, ctx->oL, ctx->occ0, ctx->occ1, obst, pred, ctx->d_pred_cc, ctx->d_pred_bc};
     hipLaunchKernelGGL(obstacle_predict_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -1643,7 +1648,7 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
     P.B = B; P.n_obs = ctx->pred_n_obs; P.n_steps = ctx->pred_n_steps; P.frame_window = frame_window; P.margin = margin;
     P.dt = c.dt; P.max_accel = c.max_accel; P.max_speed = c.max_speed; P.thr = ctx->col_radius + ctx->ocol_radius; // min_distance: 2 * radius, or car radius + bicycle radius
     P.thr_sq = jsim_sqrt_threshold(P.thr);
-    P.pxy = ctx->d_pxy; P.pcc = ctx->d_pcc; P.poff = ctx->d_poff; P.pred_cc = ctx->d_pred_cc;
+    P.pxy = ctx->d_pxy; P.pcc = ctx->d_pcc; P.poff = ctx->d_poff; P.pred_cc = ctx->d_pred_cc; P.pred_bc = ctx->d_pred_bc;
     P.x0 = x0; P.path_id = path_id; P.traj_idx = (long long *)traj_idx; P.prev_path_len = prev_path_len; P.path_len = path_len;
     P.col_flag = col_flag; P.col_xy = col_xy; P.first_idx = first_idx; P.status = status;
     P.dbg_res_idx = dbg_res_idx; P.dbg_n_res = dbg_n_res;
@@ -1751,7 +1756,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
             if (rc) return rc;
             ctx->pred_n_obs = n_obs; ctx->pred_n_steps = n_steps;
             if (n_obs > 0) {
-                ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, obs_get, nullptr, ctx->d_pred_cc};
+                ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, obs_get, nullptr, ctx->d_pred_cc, ctx->d_pred_bc};
                 hipLaunchKernelGGL(obstacle_predict_kernel, dim3(1), dim3(64), 0, s, OP);
             }
             rc = jsim_loop_pre_tick(ctx, B, x0, path_id, traj_idx, prev_path_len, glue_out, col_flag, nullptr, nullptr, pre_status,
@@ -1785,11 +1790,14 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
         ctx->d_pred_all = nullptr; ctx->pred_all_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_pred_all, sizeof(double2) * need_pred));
         ctx->pred_all_cap = need_pred;
+        if (ctx->d_bc_all) (void)hipFree(ctx->d_bc_all);
+        ctx->d_bc_all = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bc_all, sizeof(double4) * (need_pred / ((size_t)n_steps * 2))));
     }
     if (n_obs > 0) {
         ObsStepP SP = {n_obs, 1, ctx->have_ogeom ? ctx->oL : c.L, obs_state, obs_param, nullptr};
         hipLaunchKernelGGL(obstacle_rollout_kernel, dim3(1), dim3(64), 0, s, SP, n_ticks, ctx->d_get_all);
-        ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, ctx->d_get_all, nullptr, ctx->d_pred_all};
+        ObsP OP = {n_obs, n_steps, c.dt, ctx->oL, ctx->occ0, ctx->occ1, ctx->d_get_all, nullptr, ctx->d_pred_all, ctx->d_bc_all};
         hipLaunchKernelGGL(obstacle_predict_kernel, dim3(n_ticks), dim3(64), 0, s, OP);
         // the last get() tuples, as after n_ticks host ticks
         HIP_TRY(ctx, hipMemcpyAsync(obs_get, ctx->d_get_all + (size_t)(n_ticks - 1) * n_obs * 6, sizeof(double) * n_obs * 6,
@@ -1814,7 +1822,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     Q.pre.dt = c.dt; Q.pre.max_accel = c.max_accel; Q.pre.max_speed = c.max_speed; Q.pre.thr = ctx->col_radius + ctx->ocol_radius;
     Q.pre.thr_sq = jsim_sqrt_threshold(Q.pre.thr);
     Q.pre.pxy = ctx->d_pxy; Q.pre.pcc = ctx->d_pcc; Q.pre.poff = ctx->d_poff;
-    Q.pred_cc_all = ctx->d_pred_all; Q.traj_idx = (long long *)traj_idx; Q.prev_len = prev_path_len; Q.path_len_out = path_len;
+    Q.pred_cc_all = ctx->d_pred_all; Q.pred_bc_all = ctx->d_bc_all; Q.traj_idx = (long long *)traj_idx; Q.prev_len = prev_path_len; Q.path_len_out = path_len;
     Q.col_flag = col_flag; Q.pre_status = pre_status;
     Q.speed_cutoff = speed_cutoff ? 1 : 0; Q.cut_io = glue_out;
     launch_reg(c.T, B, s, P, K, &Q);
