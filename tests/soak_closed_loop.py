@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Test infrastructure (run by hand on an MI355X; not collected by pytest): parity on the states a closed loop actually
+visits.  The device loop runs tick by tick (solve, plant, goal / respawn); before every tick the oracle is given the SAME
+inputs the kernel is about to see (pose, remembered index, warm start) and its step is compared with the kernel's:
+statuses and indices identical, controls within 1e-7, active sets identical except where two constraint rows coincide.  (Two free-running loops cannot be compared over many ticks:
+a 1e-9 difference in a control grows by the loop's own sensitivity -- x40 per tick was seen at T = 40 while braking hard --
+until an ego sits on the other side of the `v0 <= speed` feasibility edge.  The fused K-tick launch is bit-identical to
+this tick-by-tick loop: tests/test_gpu_parity.py::test_fused_ticks_equal_single_ticks.)
+
+    python tests/soak_closed_loop.py [B=256] [ticks=150]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+pkg = importlib.import_module("av-simulation-at-intersections_amd")
+import oracle_py as O  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+S = pkg.synth
+routes = S.make_route_table()
+for r in routes:
+    S.smooth_yaw_inplace(r[:, 2])
+cx, cy, cyaw, off = S.pack_paths(routes)
+bad = 0
+for T in (13, 20, 30, 40):
+    batch = S.make_ego_batch(routes, B, T, seed=5)
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smooth=False)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    loop = pkg.ClosedLoop(eng, torch.from_numpy(batch.x0).cuda(), max_age=70)
+    p = O.make_params(T=T)
+    worst = 0.0
+    n_st = n_ti = n_mk = n_steps = n_fail = 0
+    same_it = 0
+    for k in range(K):
+        x0 = loop.x0.cpu().numpy().copy()
+        tind = eng.target_ind.cpu().numpy().copy()
+        oa = eng.oa.cpu().numpy().copy(); od = eng.od.cpu().numpy().copy()
+        loop.eng.solve(loop.x0)                                   # the step of this tick (outputs in place)
+        torch.cuda.synchronize()
+        ref = O.mpc_step_batch(p, x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off, tind, oa, od, n_threads=16)
+        st = eng.status.cpu().numpy()
+        ok = (st == 0) & (ref["status"] == 0)
+        n_st += int((st != ref["status"]).sum()); n_fail += int((ref["status"] != 0).sum())
+        n_ti += int((eng.target_ind.cpu().numpy() != ref["target_ind"]).sum())
+        n_mk += int((eng.active_mask.cpu().numpy().view(np.uint32) != ref["active_mask"]).any(axis=1).sum())
+        if ok.any():
+            worst = max(worst, float(np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max()), float(np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max()))
+        same_it += int((eng.n_iter.cpu().numpy() == ref["n_iter"]).sum())
+        n_steps += B
+        # the rest of the tick on the device (plant, goal / respawn), from the kernel's own solution
+        pkg._cabi.check(eng.lib.jsim_loop_advance(
+            eng._ctx, eng.B, loop.x0.data_ptr(), eng.oa.data_ptr(), eng.od.data_ptr(), eng.status.data_ptr(), eng.di_ai.data_ptr(),
+            eng.target_ind.data_ptr(), eng.path_id.data_ptr(), eng.path_len.data_ptr(), loop.x0_spawn.data_ptr(),
+            loop.target_spawn.data_ptr(), loop.age.data_ptr(), loop.max_age, None, loop.tick_counter.data_ptr(), 0,
+            loop.n_respawn.data_ptr(), eng._stream()), eng._ctx, "jsim_loop_advance")
+    print(f"T={T:2d}: {n_steps} closed-loop steps ({int(loop.n_respawn.item())} respawns, {n_fail} reference-failure steps): max|du| {worst:.2e}, "
+          f"status diffs {n_st}, target_ind diffs {n_ti}, active-set diffs {n_mk}, n_iter identical {100.0 * same_it / n_steps:.2f} %", flush=True)
+    # Active-set differences with identical u*: two COINCIDENT rows (v_1 <= speed and a_0 <= MAX_ACCEL are the same half-space
+    # when v_0 = speed - MAX_ACCEL * dt exactly, which an ego accelerating flat out onto the speed limit does hit).  Their
+    # multipliers are not unique -- lambda_VU * dt + lambda_AU is -- and which of the two rows enters is a tie in the entering
+    # rule that rounding may break either way.  Counted, not failed, as long as they stay below 0.1 % of the steps.
+    bad += n_st + n_ti + (n_mk > n_steps // 1000) + (worst > 1e-7)
+print("CLOSED-LOOP SOAK", "CLEAN" if bad == 0 else f"FOUND {bad} DIFFERENCES")
+sys.exit(0 if bad == 0 else 1)
