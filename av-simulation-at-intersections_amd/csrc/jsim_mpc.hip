@@ -36,11 +36,15 @@
 #include "jsim_mpc.h"
 
 #define JSIM_VIOL_TOL 1e-10
-// Entering-row key: viol^2 / (n'H^-1 n) with its low 9 mantissa bits cleared (keys closer than 2^-43 relative count as
-// tied and go to the lowest canonical row id, < 512).  The register kernel stores 511 - id in those 9 bits.
+// Entering-row key: viol^2 / (n'H^-1 n) with its low 20 mantissa bits cleared (keys closer than 2^-32 relative count as
+// tied and go to the lowest canonical row id, < 512).  The register kernels store 511 - id in the lowest 9 of them.
+// 20 bits: rows that COINCIDE (v_1 <= speed and a_0 <= MAX_ACCEL when v_0 = speed - MAX_ACCEL * dt) have mathematically equal keys
+// whose roundings differ by a few ulps; with 9 cleared bits one such pair in ~100 straddled a truncation boundary and the kernel and
+// the oracle entered different rows of the pair (same u*, different but equally valid multipliers).
+#define JSIM_KEY_MASK 0xFFFFF
 __device__ __forceinline__ double jsim_key_trunc(double k)
 {
-    return __hiloint2double(__double2hiint(k), __double2loint(k) & ~511);
+    return __hiloint2double(__double2hiint(k), __double2loint(k) & ~JSIM_KEY_MASK);
 }
 // Dual ratio test: a step length keeps its upper 57 bits (the low 7 are cleared; the register kernel stores the
 // working-set position there), steps closer than 2^-45 relative are ties -> lowest position.
@@ -54,7 +58,7 @@ __device__ __forceinline__ double jsim_ratio_pack(double t, int k)
 }
 __device__ __forceinline__ double jsim_key_pack(double k, int id)
 {
-    return __hiloint2double(__double2hiint(k), (__double2loint(k) & ~511) | (511 - id));
+    return __hiloint2double(__double2hiint(k), (__double2loint(k) & ~JSIM_KEY_MASK) | (511 - id));
 }
 #define JSIM_DEP_TOL 1e-18
 #define JSIM_ACT_TOL 1e-9

@@ -401,13 +401,13 @@ int orc_build_qp(const orc_params *p, const double *xref, const double *xbar, co
 #define ORC_VIOL_TOL 1e-10
 #define ORC_DEP_TOL 1e-18 /* ||d2||^2 <= tol * ||d||^2  => normal is in the span of the working set */
 
-/* Entering-row key with its low 9 mantissa bits cleared: keys closer than 2^-43 relative are ties -> lowest row id.
+/* Entering-row key with its low 20 mantissa bits cleared: keys closer than 2^-32 relative are ties -> lowest row id.
  * (Same rule as csrc/jsim_mpc.hip: jsim_key_trunc.) */
 static double orc_key_trunc(double k)
 {
     uint64_t b;
     memcpy(&b, &k, 8);
-    b &= ~(uint64_t)511;
+    b &= ~(uint64_t)0xFFFFF;
     memcpy(&k, &b, 8);
     return k;
 }

@@ -2,7 +2,7 @@
 """Test infrastructure (run by hand on an MI355X; not collected by pytest): parity on the states a closed loop actually
 visits.  The device loop runs tick by tick (solve, plant, goal / respawn); before every tick the oracle is given the SAME
 inputs the kernel is about to see (pose, remembered index, warm start) and its step is compared with the kernel's:
-statuses and indices identical, controls within 1e-7, active sets identical except where two constraint rows coincide.  (Two free-running loops cannot be compared over many ticks:
+statuses, indices and active sets identical, controls within 1e-7.  (Two free-running loops cannot be compared over many ticks:
 a 1e-9 difference in a control grows by the loop's own sensitivity -- x40 per tick was seen at T = 40 while braking hard --
 until an ego sits on the other side of the `v0 <= speed` feasibility edge.  The fused K-tick launch is bit-identical to
 this tick-by-tick loop: tests/test_gpu_parity.py::test_fused_ticks_equal_single_ticks.)
@@ -63,10 +63,9 @@ for T in (13, 20, 30, 40):
             loop.n_respawn.data_ptr(), eng._stream()), eng._ctx, "jsim_loop_advance")
     print(f"T={T:2d}: {n_steps} closed-loop steps ({int(loop.n_respawn.item())} respawns, {n_fail} reference-failure steps): max|du| {worst:.2e}, "
           f"status diffs {n_st}, target_ind diffs {n_ti}, active-set diffs {n_mk}, n_iter identical {100.0 * same_it / n_steps:.2f} %", flush=True)
-    # Active-set differences with identical u*: two COINCIDENT rows (v_1 <= speed and a_0 <= MAX_ACCEL are the same half-space
-    # when v_0 = speed - MAX_ACCEL * dt exactly, which an ego accelerating flat out onto the speed limit does hit).  Their
-    # multipliers are not unique -- lambda_VU * dt + lambda_AU is -- and which of the two rows enters is a tie in the entering
-    # rule that rounding may break either way.  Counted, not failed, as long as they stay below 0.1 % of the steps.
-    bad += n_st + n_ti + (n_mk > n_steps // 1000) + (worst > 1e-7)
+    # (Coincident rows -- v_1 <= speed and a_0 <= MAX_ACCEL are the same half-space when v_0 = speed - MAX_ACCEL * dt exactly,
+    # which an ego accelerating flat out onto the speed limit does hit -- have non-unique multipliers and equal entering keys:
+    # this soak is what showed that a 9-bit tie band let rounding pick different rows of such a pair; it is 20 bits now.)
+    bad += n_st + n_ti + n_mk + (worst > 1e-7)
 print("CLOSED-LOOP SOAK", "CLEAN" if bad == 0 else f"FOUND {bad} DIFFERENCES")
 sys.exit(0 if bad == 0 else 1)
