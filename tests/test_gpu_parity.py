@@ -568,6 +568,40 @@ def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T, max_age):
     assert int((a["pst"] != 0).sum()) == 0     # the glue never lost its footing (respawned egos restart their progress index)
 
 
+@pytest.mark.parametrize("T,K", ((40, 12), (20, 25)))
+def test_closed_loop_visited_states_against_oracle(pkg, oracle, routes, T, K):
+    """Parity on states a closed loop visits (the by-hand soak tests/soak_closed_loop.py in small): before every tick the
+    oracle gets the kernel's inputs.  T = 40 with this seed reaches, at tick 8, an ego whose rows `v_1 <= speed` and
+    `a_0 <= MAX_ACCEL` coincide (v_0 = speed - MAX_ACCEL * dt): equal entering keys up to rounding, non-unique multipliers --
+    with a 9-bit tie band kernel and oracle entered different rows of the pair; the band is 20 bits (jsim_key_trunc)."""
+    B = 64
+    batch = pkg.synth.make_ego_batch(routes, 256, T, seed=5)          # the soak's batch; its first 64 egos
+    sub = pkg.synth.EgoBatch(x0=batch.x0[:B].copy(), path_id=batch.path_id[:B].copy(), path_len=batch.path_len[:B].copy(),
+                             target_ind=batch.target_ind[:B].copy(), speed=batch.speed[:B].copy(), oa=batch.oa[:B].copy(),
+                             od=batch.od[:B].copy())
+    eng = _engine(pkg, routes, sub, T)
+    loop = pkg.ClosedLoop(eng, torch.from_numpy(sub.x0).to(eng.device), max_age=70)
+    p = oracle.make_params(T=T)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    worst = 0.0
+    for k in range(K):
+        x0 = loop.x0.cpu().numpy().copy(); tind = eng.target_ind.cpu().numpy().copy()
+        oa = eng.oa.cpu().numpy().copy(); od = eng.od.cpu().numpy().copy()
+        loop.tick()
+        torch.cuda.synchronize()
+        # loop.tick() has advanced the plant; status / controls / masks / target_ind are still this tick's solve
+        ref = oracle.mpc_step_batch(p, x0, sub.path_id, sub.path_len, sub.speed, cx, cy, cyaw, off, tind, oa, od, n_threads=8)
+        st = eng.status.cpu().numpy()
+        assert np.array_equal(st, ref["status"]), k
+        assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"]), k
+        ok = st == 0
+        resp = (loop.age.cpu().numpy() == 0)                          # respawned egos had oa / od / target_ind reset by the advance
+        keep = ok & ~resp
+        worst = max(worst, float(np.abs(eng.oa.cpu().numpy() - ref["oa"])[keep].max()), float(np.abs(eng.od.cpu().numpy() - ref["od"])[keep].max()))
+        assert np.array_equal(eng.target_ind.cpu().numpy()[~resp], ref["target_ind"][~resp]), k
+    assert worst <= 1e-7, worst
+
+
 def test_scripted_obstacles_vs_reference(pkg, routes):
     g = load_golden("obstacles_scripted.npz")
     eng = pkg.BatchedMPC(routes, np.zeros(1, dtype=np.int32), dl=pkg.synth.DL, T=13, smooth=False)
