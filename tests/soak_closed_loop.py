@@ -7,7 +7,7 @@ a 1e-9 difference in a control grows by the loop's own sensitivity -- x40 per ti
 until an ego sits on the other side of the `v0 <= speed` feasibility edge.  The fused K-tick launch is bit-identical to
 this tick-by-tick loop: tests/test_gpu_parity.py::test_fused_ticks_equal_single_ticks.)
 
-    python tests/soak_closed_loop.py [B=256] [ticks=150]
+    python tests/soak_closed_loop.py [B=256] [ticks=150] [horizons=13,20,30,40]
 """
 import importlib
 import os
@@ -30,7 +30,7 @@ for r in routes:
     S.smooth_yaw_inplace(r[:, 2])
 cx, cy, cyaw, off = S.pack_paths(routes)
 bad = 0
-for T in (13, 20, 30, 40):
+for T in ([int(t) for t in sys.argv[3].split(',')] if len(sys.argv) > 3 else (13, 20, 30, 40)):
     batch = S.make_ego_batch(routes, B, T, seed=5)
     eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, smooth=False)
     eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
