@@ -4,7 +4,7 @@ afford), every horizon that has a register kernel plus one that takes the LDS ke
 |du|, how many active sets / statuses / target indices differ and how often the iteration count is identical.
 Test infrastructure (lives under tests/ because it loads oracle/ as the checker; not collected by pytest -- run by hand):
 
-    python tests/soak_parity.py [seeds=8] [B=512]
+    python tests/soak_parity.py [seeds=8] [B=512] [jerk]
 """
 import importlib
 import os
@@ -22,6 +22,9 @@ import oracle_py as oracle  # noqa: E402
 
 NSEED = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+JERK = len(sys.argv) > 3 and sys.argv[3] == "jerk"   # the acceleration-state variant (lib/mpc_jerk.py) instead of lib/mpc.py
+JCFG = {"NX": 5, "w_perp": 10.0, "w_para": 1.0, "R": [0.01, 0.01], "Rd": [0.3, 1.0], "Q_v_yaw": [0.0, 0.5], "Qf": [1.0, 1.0, 0.0, 0.5],
+        "STOP_SPEED": 0.5 / 3.6, "MAX_DECEL": -5, "JERK_WEIGHT": 1.0}
 S = pkg.synth
 routes = S.make_route_table()
 for r in routes:
@@ -35,11 +38,17 @@ for T in (13, 20, 30, 40, 25):
     t0 = time.time()
     for seed in range(100, 100 + NSEED):
         batch = S.make_ego_batch(routes, B, T, seed=seed, truncate=(seed % 2 == 0), near_end_frac=0.15)
-        eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device="cuda:0", smooth=False)
+        if JERK:
+            from dataclasses import replace
+            batch.speed[:] = 30 / 3.6                     # x[2,:] <= Simulation.MAX_SPEED
+            eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device="cuda:0", smooth=False,
+                                 config=replace(pkg.mpc_jerk.config, T=T))
+        else:
+            eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device="cuda:0", smooth=False)
         eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
         eng.solve(torch.from_numpy(batch.x0).cuda())
         torch.cuda.synchronize()
-        p = oracle.make_params(T=T)
+        p = oracle.make_params(T=T, config=JCFG if JERK else None)
         ref = oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off,
                                     batch.target_ind, batch.oa, batch.od)
         st = eng.status.cpu().numpy()
