@@ -78,19 +78,29 @@ class BatchedMPC:
         self.full_len = torch.from_numpy(full).to(dev)
         sp = np.broadcast_to(np.asarray(speed, dtype=np.float64), (B,)).copy()
         self.speed = torch.from_numpy(sp).to(dev)
-        f64 = dict(dtype=torch.float64, device=dev)
-        self.target_ind = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.oa = torch.zeros(B, T, **f64)       # reference: None -> zeros (mpc.py:225-227)
-        self.od = torch.zeros(B, T, **f64)
-        self.ox = torch.zeros(B, T + 1, **f64)
-        self.oy = torch.zeros(B, T + 1, **f64)
-        self.ov = torch.zeros(B, T + 1, **f64)
-        self.oyaw = torch.zeros(B, T + 1, **f64)
-        self.xref = torch.zeros(B, 4, T + 1, **f64)
-        self.active_mask = torch.zeros(B, (8 * T + 31) // 32, dtype=torch.int32, device=dev)
-        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.n_iter = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.di_ai = torch.zeros(B, 2, **f64)    # (di, ai), both 0.0 initially (mpc.py:274-275)
+        # controller state + step outputs: typed views of ONE device allocation, so that a caller who wants everything on the
+        # host (the single-ego drop-in) pays one device->host copy per step instead of one per array
+        MW = (8 * T + 31) // 32
+        spec = [("target_ind", torch.int64, (B,)), ("oa", torch.float64, (B, T)), ("od", torch.float64, (B, T)),
+                ("ox", torch.float64, (B, T + 1)), ("oy", torch.float64, (B, T + 1)), ("ov", torch.float64, (B, T + 1)),
+                ("oyaw", torch.float64, (B, T + 1)), ("xref", torch.float64, (B, 4, T + 1)), ("di_ai", torch.float64, (B, 2)),
+                ("active_mask", torch.int32, (B, MW)), ("status", torch.int32, (B,)), ("n_iter", torch.int32, (B,))]
+        self._arena_layout = {}
+        nbytes = 0
+        for name, dt, shape in spec:
+            n = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            self._arena_layout[name] = (nbytes, n, dt, shape)
+            nbytes += (n + 7) & ~7
+        self._arena = torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=dev)   # oa/od zeros = the reference's None (mpc.py:225-227); di = ai = 0 (:274-275)
+        for name, (o, n, dt, shape) in self._arena_layout.items():
+            setattr(self, name, self._arena[o:o + n].view(dt).view(shape))
+
+    def read_back(self) -> dict:
+        """Everything the step wrote, on the host, with ONE synchronising device->host copy: a dict of numpy views
+        (target_ind, oa, od, ox, oy, ov, oyaw, xref, di_ai, active_mask, status, n_iter)."""
+        host = self._arena.cpu().numpy()
+        return {name: host[o:o + n].view(torch.empty((), dtype=dt).numpy().dtype).reshape(shape)
+                for name, (o, n, dt, shape) in self._arena_layout.items()}
 
     # ------------------------------------------------------------------ paths
     def _upload_paths(self):

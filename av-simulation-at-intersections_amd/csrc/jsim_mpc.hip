@@ -1277,6 +1277,23 @@ static int fail(jsim_ctx *ctx, int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(ctx, -5, "%s failed: %s", #call, hipGetErrorString(e_));             \
     } while (0)
 
+// Every entry point that launches, allocates or copies runs on the context's device and leaves the caller's current device
+// as it found it (two contexts on different GPUs in one process; a caller whose current device is another one).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 extern "C" int jsim_abi_version(void) { return JSIM_ABI_VERSION; }
 
 extern "C" const char *jsim_last_error(const jsim_ctx *ctx) { return ctx ? ctx->err : g_err; }
@@ -1297,7 +1314,7 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -22, "jsim_mpc_create: device %d of %d", device_id, ndev);
     const size_t lds_bytes = jsim_lds_doubles(cfg->T, cfg->nx == 5) * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(nullptr, -22, "jsim_mpc_create: T=%d needs %zu B of LDS (> 160 KiB)", cfg->T, lds_bytes);
-    HIP_TRY(nullptr, hipSetDevice(device_id));
+    DeviceGuard dev_guard(device_id);   // the caller's current device is left as it was
     // dynamic LDS above the 64 KiB default has to be granted per kernel; done once here so that the step call
     // itself is pure launches (it may be captured into a hipGraph)
     HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1338,7 +1355,7 @@ static void free_paths(jsim_ctx *c)
 extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard dev_guard(ctx->device);
     free_paths(ctx);
     if (ctx->d_pred_cc) (void)hipFree(ctx->d_pred_cc);
     if (ctx->d_get_all) (void)hipFree(ctx->d_get_all);
@@ -1370,12 +1387,12 @@ extern "C" int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double 
                                   const int64_t *path_off, int32_t n_paths)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_paths: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (!cx || !cy || !cyaw || !path_off || n_paths < 1) return fail(ctx, -22, "jsim_mpc_set_paths: bad argument");
     if (path_off[0] != 0) return fail(ctx, -22, "jsim_mpc_set_paths: path_off[0] must be 0");
     for (int i = 0; i < n_paths; ++i)
         if (path_off[i + 1] <= path_off[i]) return fail(ctx, -22, "jsim_mpc_set_paths: path %d is empty", i);
     const long long N = path_off[n_paths];
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_paths(ctx);
     // resident path table: xy interleaved (one 16-byte load per point in the nearest-index scan) + yaw
     double2 *h = new (std::nothrow) double2[N];
@@ -1420,6 +1437,7 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
                        double *xbar, int64_t *ref_idx, double *H, double *g, double *lam, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_step: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0) return fail(ctx, -22, "jsim_mpc_step: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status)
@@ -1477,12 +1495,12 @@ extern "C" int jsim_plant_step(jsim_ctx *ctx, int32_t B, double *x0, const doubl
                                const int32_t *status, double *di_ai, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_plant_step: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0) return fail(ctx, -22, "jsim_plant_step: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !oa || !od || !status || !di_ai) return fail(ctx, -22, "jsim_plant_step: null device pointer");
     const jsim_cfg &c = ctx->cfg;
     PlantP P = {B, c.T, c.dt, c.L, c.max_steer, c.max_speed, c.min_speed, c.max_decel, ctx->d_pe};
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, x0, oa, od, status, di_ai);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -1493,6 +1511,7 @@ extern "C" int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const doub
                                             const double *oy, double *deviation, int32_t *is_goal, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_xref_deviation_goal: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0) return fail(ctx, -22, "jsim_mpc_xref_deviation_goal: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !path_id || !path_len || !target_ind || (deviation && (!ox || !oy)))
@@ -1500,7 +1519,6 @@ extern "C" int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const doub
     if (!ctx->d_pxy) return fail(ctx, -22, "jsim_mpc_xref_deviation_goal: no paths set");
     const jsim_cfg &c = ctx->cfg;
     GoalP P = {B, c.T, c.goal_dis, c.stop_speed, ctx->d_pxy, ctx->d_pyaw, ctx->d_poff};
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(deviation_goal_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, x0, path_id,
                        path_len, (const long long *)target_ind, ox, oy, deviation, is_goal);
     HIP_TRY(ctx, hipGetLastError());
@@ -1513,6 +1531,7 @@ extern "C" int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *o
                                  double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_advance: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0) return fail(ctx, -22, "jsim_loop_advance: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !oa || !od || !status || !di_ai || !target_ind || !path_id || !path_len || !x0_spawn || !target_spawn || !age)
@@ -1549,6 +1568,7 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
                                   double *hist, int32_t *tick, int32_t hist_cap, uint64_t *n_respawn, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_run_ticks: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0 || n_ticks < 0) return fail(ctx, -22, "jsim_mpc_run_ticks: B=%d n_ticks=%d", B, n_ticks);
     if (B == 0 || n_ticks == 0) return 0;
     if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status || !di_ai || !x0_spawn ||
@@ -1601,8 +1621,8 @@ static double jsim_sqrt_threshold(double thr)
 extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_set_geometry: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (!(radius > 0)) return fail(ctx, -22, "jsim_loop_set_geometry: radius must be positive");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->cc0 = cc_front; ctx->cc1 = cc_rear; ctx->col_radius = radius; ctx->have_geom = 1;
     if (!ctx->have_ogeom) { ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = ctx->cfg.L; }
     if (!ctx->d_pred_cc) HIP_TRY(ctx, hipMalloc(&ctx->d_pred_cc, sizeof(double2) * JSIM_MAX_OBS * JSIM_MAX_PRED * 2));
@@ -1613,6 +1633,7 @@ extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_
 extern "C" int jsim_loop_set_obstacle_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, double radius, double wheelbase)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_set_obstacle_geometry: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (!(radius > 0) || !(wheelbase > 0)) return fail(ctx, -22, "jsim_loop_set_obstacle_geometry: radius and wheelbase must be positive");
     ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = wheelbase; ctx->have_ogeom = 1;
     return 0;
@@ -1622,6 +1643,7 @@ extern "C" int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const d
                                            void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_predict_obstacles: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (!ctx->have_geom) return fail(ctx, -22, "jsim_loop_predict_obstacles: jsim_loop_set_geometry has not been called");
     if (n_obs < 0 || n_obs > JSIM_MAX_OBS || n_steps < 1 || n_steps > JSIM_MAX_PRED)
         return fail(ctx, -22, "jsim_loop_predict_obstacles: n_obs=%d (max %d), n_steps=%d (max %d)", n_obs, JSIM_MAX_OBS, n_steps, JSIM_MAX_PRED);
@@ -1640,6 +1662,7 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
                                   int32_t *dbg_res_idx, int32_t *dbg_n_res, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_pre_tick: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0 || frame_window < 0 || frame_window > 32 || margin < 0) return fail(ctx, -22, "jsim_loop_pre_tick: bad argument");
     if (B == 0) return 0;
     if (!x0 || !path_id || !traj_idx || !prev_path_len || !path_len || !col_flag || !status)
@@ -1665,7 +1688,7 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
 extern "C" int jsim_mpc_set_path_speed(jsim_ctx *ctx, const double *cv)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_path_speed: null ctx");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev_guard(ctx->device);
     if (ctx->d_pcv) { (void)hipFree(ctx->d_pcv); ctx->d_pcv = nullptr; }
     if (!cv) return 0; // back to the plain controller (no speed reference)
     if (ctx->n_points <= 0) return fail(ctx, -22, "jsim_mpc_set_path_speed: call jsim_mpc_set_paths first");
@@ -1705,6 +1728,7 @@ extern "C" int jsim_loop_obstacles(jsim_ctx *ctx, int32_t n_obs, double *state, 
                                    void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_obstacles: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (n_obs < 0 || n_obs > JSIM_MAX_OBS) return fail(ctx, -22, "jsim_loop_obstacles: n_obs=%d (max %d)", n_obs, JSIM_MAX_OBS);
     if (n_obs == 0) return 0;
     if (!state || !param) return fail(ctx, -22, "jsim_loop_obstacles: null device pointer");
@@ -1736,6 +1760,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
                                       int32_t n_steps, int32_t speed_cutoff, void *stream)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_run_scenario: null ctx");
+    DeviceGuard dev_guard(ctx->device);
     if (B < 0 || n_ticks < 0 || frame_window < 0 || frame_window > 32 || margin < 0)
         return fail(ctx, -22, "jsim_loop_run_scenario: bad argument");
     if (B == 0 || n_ticks == 0) return 0;
@@ -1749,7 +1774,6 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     if (!ctx->d_pxy || !ctx->d_pcc || !ctx->have_geom) return fail(ctx, -22, "jsim_loop_run_scenario: paths / geometry not set");
     const jsim_cfg &c = ctx->cfg;
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (speed_cutoff && !ctx->cv_cut)
         return fail(ctx, -22, "jsim_loop_run_scenario: the speed-cut-off glue needs jsim_mpc_set_speed_cutoff first");
     int32_t *const glue_out = speed_cutoff ? const_cast<int32_t *>(ctx->cv_cut) : path_len; // where the cut-off index goes

@@ -79,17 +79,23 @@ class MPC:
         self._x0 = torch.zeros(1, 4, dtype=torch.float64, device=device)
         self._engine: Optional[BatchedMPC] = None
         self._full: Optional[np.ndarray] = None
+        self._rebound = False
+        self._oa_dev = self._od_dev = None   # the host arrays whose values the device's warm start currently holds
         self._bind(np.stack([np.asarray(cx, dtype=np.float64), np.asarray(cy, dtype=np.float64),
                              np.asarray(cyaw, dtype=np.float64)], axis=1))
 
-    # a (re)upload of the path table; controller state (target_ind, warm start) survives, as in the reference
+    # a (re)upload of the path table: the controller state lives in this object (target_ind, oa, odelta, di -- kept across
+    # set_trajectory_fromarray exactly like the reference, main/lib/mpc.py:279-282) and is pushed to the new engine by step()
+    def _make_engine(self, full: np.ndarray) -> BatchedMPC:
+        return BatchedMPC([full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
+                          speed=self.speed, dt=self.dt, T=T, config=config, device=self._device, smooth=False)
+
     def _bind(self, full: np.ndarray):
         if self._engine is not None:
             self._engine.close()
         self._full = np.ascontiguousarray(full, dtype=np.float64).copy()
-        self._engine = BatchedMPC([self._full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
-                                  speed=self.speed, dt=self.dt, T=T, config=config, device=self._device,
-                                  smooth=False)
+        self._engine = self._make_engine(self._full)
+        self._rebound = True
 
     def set_trajectory_fromarray(self, trajectory: np.ndarray):
         self.cx = trajectory[:, 0]
@@ -101,35 +107,41 @@ class MPC:
         else:
             self._bind(np.asarray(trajectory[:, :3], dtype=np.float64))
 
+    def _failure_decel(self) -> float:
+        return MAX_DECEL  # mpc.py:301 (the variants apply their own module constant)
+
     def step(self, state) -> Tuple[float, float]:
         eng = self._engine
-        # controller state lives on the device between ticks; mirror what the caller may have changed
+        # the controller state is resident on the device between ticks; what the caller (or a re-bound path) may have
+        # changed on the host side is mirrored first: the remembered index, the warm start (None -> zeros, mpc.py:225-227)
         eng.target_ind.fill_(int(self.target_ind))
         if self.oa is None or self.odelta is None:
-            eng.oa.zero_(); eng.od.zero_()  # mpc.py:225-227
+            eng.oa.zero_(); eng.od.zero_()
+        elif self._rebound or self.oa is not self._oa_dev or self.odelta is not self._od_dev:
+            eng.load_state(oa=np.asarray(self.oa, dtype=np.float64)[None], od=np.asarray(self.odelta, dtype=np.float64)[None])
+        self._rebound = False
         self._x0.copy_(torch.tensor([[state.x, state.y, state.v, state.yaw]], dtype=torch.float64))  # mpc.py:291
         eng.solve(self._x0)
-        status = int(eng.status.item())
+        out = eng.read_back()           # one synchronising device->host copy
+        status = int(out["status"][0])
         self.status = status
         if status == 2:
             raise Exception("something wrong")  # main/lib/trajectories.py:120
-        self.n_iter = int(eng.n_iter.item())
-        self.target_ind = int(eng.target_ind.item())
-        self.xref = eng.xref[0].cpu().numpy()
+        self.n_iter = int(out["n_iter"][0])
+        self.target_ind = int(out["target_ind"][0])
+        self.xref = out["xref"][0]
         if status == 0:
-            self.oa = eng.oa[0].cpu().numpy()
-            self.odelta = eng.od[0].cpu().numpy()
-            self.ox = eng.ox[0].cpu().numpy()
-            self.oy = eng.oy[0].cpu().numpy()
-            self.ov = eng.ov[0].cpu().numpy()
-            self.oyaw = eng.oyaw[0].cpu().numpy()
-            self.active_constraints = eng.active_indices(0)
+            self.oa, self.odelta = out["oa"][0], out["od"][0]
+            self.ox, self.oy, self.ov, self.oyaw = out["ox"][0], out["oy"][0], out["ov"][0], out["oyaw"][0]
+            words = out["active_mask"][0].view(np.uint32)
+            self.active_constraints = [i for i in range(8 * eng.T) if (int(words[i >> 5]) >> (i & 31)) & 1]
             self.di, self.ai = float(self.odelta[0]), float(self.oa[0])
         else:
             print("Error: Cannot solve mpc...", file=sys.stderr)  # mpc.py:208
             self.oa = self.odelta = self.ox = self.oy = self.oyaw = self.ov = None
             self.active_constraints = []
-            self.ai = MAX_DECEL  # mpc.py:301
+            self.ai = self._failure_decel()
+        self._oa_dev, self._od_dev = self.oa, self.odelta   # these very arrays are what the device holds
         return self.di, self.ai
 
     def get_current_xref_deviation(self):

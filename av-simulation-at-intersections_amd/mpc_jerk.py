@@ -45,18 +45,12 @@ class MPC(_BaseMPC):
                  device: str = "cuda:0"):
         super().__init__(cx, cy, cyaw, dl, car_dimensions, speed=config.MAX_SPEED, dt=dt, device=device)  # x[2,:] <= Simulation.MAX_SPEED (:194)
 
-    def _bind(self, full: np.ndarray):
-        if self._engine is not None:
-            self._engine.close()
-        self._full = np.ascontiguousarray(full, dtype=np.float64).copy()
-        self._engine = BatchedMPC([self._full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
-                                  speed=self.speed, dt=self.dt, T=T, config=config, device=self._device, smooth=False)
+    def _make_engine(self, full: np.ndarray) -> BatchedMPC:
+        return BatchedMPC([full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
+                          speed=self.speed, dt=self.dt, T=T, config=config, device=self._device, smooth=False)
 
-    def step(self, state) -> Tuple[float, float]:
-        di, ai = super().step(state)
-        if self.status == 1:
-            self.ai = MAX_DECEL      # this module's MAX_DECEL (-5), main/lib/mpc_jerk.py:311
-        return self.di, self.ai
+    def _failure_decel(self) -> float:
+        return MAX_DECEL     # this module's MAX_DECEL (-5), main/lib/mpc_jerk.py:311
 
     def is_goal(self, state) -> bool:
         import math

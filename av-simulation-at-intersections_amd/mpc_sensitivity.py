@@ -55,19 +55,16 @@ class MPC(_BaseMPC):
         self._cfg_now = _load(CONFIG_PATH)
         super().__init__(cx, cy, cyaw, dl, car_dimensions, speed=MAX_SPEED, dt=dt, device=device)
 
-    def _bind(self, full: np.ndarray):
-        if self._engine is not None:
-            self._engine.close()
-        self._full = np.ascontiguousarray(full, dtype=np.float64).copy()
-        self._engine = BatchedMPC([self._full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
-                                  speed=self.speed, dt=self.dt, T=T, config=self._cfg_now, device=self._device, smooth=False)
+    def _make_engine(self, full: np.ndarray) -> BatchedMPC:
+        return BatchedMPC([full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
+                          speed=self.speed, dt=self.dt, T=T, config=self._cfg_now, device=self._device, smooth=False)
+
+    def _failure_decel(self) -> float:
+        return MAX_DECEL                              # the module constant read at import (:41), not the file's current value
 
     def step(self, state) -> Tuple[float, float]:
         cfg = _load(CONFIG_PATH)                      # the reference opens the file in every solve (:153-154)
         if cfg != self._cfg_now:
             self._engine.update_config(cfg)
             self._cfg_now = cfg
-        di, ai = super().step(state)
-        if self.status == 1:
-            self.ai = MAX_DECEL                       # the module constant read at import (:41), not the file's current value
-        return self.di, self.ai
+        return super().step(state)

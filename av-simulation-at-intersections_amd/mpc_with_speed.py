@@ -40,36 +40,42 @@ class MPC(_BaseMPC):
     def __init__(self, cx: np.ndarray, cy: np.ndarray, cv: np.ndarray, cyaw: np.ndarray, dl: float, car_dimensions,
                  dt: float = 0.2, device: str = "cuda:0"):
         self.cv = cv
-        self._cut = 999
         super().__init__(cx, cy, cyaw, dl, car_dimensions, speed=30.0 / 3.6, dt=dt, device=device)  # limit = Simulation.MAX_SPEED
 
-    def _bind(self, full: np.ndarray):
-        if self._engine is not None:
-            self._engine.close()
-        self._full = np.ascontiguousarray(full, dtype=np.float64).copy()
+    def _make_engine(self, full: np.ndarray) -> BatchedMPC:
         cv = np.ascontiguousarray(self.cv, dtype=np.float64)
-        if len(cv) != len(self._full):
-            cv = np.full(len(self._full), MAX_SPEED)
-        self._engine = BatchedMPC([self._full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
-                                  speed=self.speed, dt=self.dt, T=T, config=config, device=self._device, smooth=False,
-                                  cv=[cv])
+        if len(cv) != len(full):
+            raise ValueError("cv must have one entry per path point")
+        self._cv_dev = cv.copy()                                    # what the device's speed reference holds (before the cut-off)
+        return BatchedMPC([full], [0], dl=self.dl, L=self.car_dimensions.distance_back_to_front_wheel,
+                          speed=self.speed, dt=self.dt, T=T, config=config, device=self._device, smooth=False, cv=[cv])
 
     def set_trajectory_fromarray(self, trajectory: np.ndarray, cutoff_idx: int = 999):
-        self.cv = np.full(trajectory.shape[0], MAX_SPEED)          # :280
+        m = trajectory.shape[0]
+        self.cx, self.cy, self.cyaw = trajectory[:, 0], trajectory[:, 1], trajectory[:, 2]
+        self.cv = np.full(m, MAX_SPEED)                             # :280 -- EVERY call resets the reference to MAX_SPEED
+        cut = -1
         if cutoff_idx != 999:
-            self.cv[cutoff_idx:] = 0                               # :281-282
-        same = (self._full is not None and trajectory.shape[0] <= self._full.shape[0]
-                and np.array_equal(trajectory[:, :3], self._full[:trajectory.shape[0]])
-                and self._engine.cv is not None and np.all(self._engine.cv[0] == MAX_SPEED))
-        if same:
-            self.cx, self.cy, self.cyaw = trajectory[:, 0], trajectory[:, 1], trajectory[:, 2]
-            self._engine.set_path_len(np.array([trajectory.shape[0]], dtype=np.int32))
-        else:
-            super().set_trajectory_fromarray(trajectory)           # re-uploads path + a MAX_SPEED reference
-        self._engine.set_speed_cutoff(np.array([cutoff_idx if cutoff_idx != 999 else -1], dtype=np.int32))
+            self.cv[cutoff_idx:] = 0                                # :281-282 (a negative index counts from the end, as in Python)
+            cut = min(cutoff_idx, m) if cutoff_idx >= 0 else max(m + cutoff_idx, 0)
+        prefix = (m <= self._full.shape[0] and np.array_equal(trajectory[:, :3], self._full[:m])
+                  and np.all(self._cv_dev[:m] == MAX_SPEED))
+        if prefix:   # same points, and the device's reference is already MAX_SPEED there: only the visible length changes
+            self._engine.set_path_len(np.array([m], dtype=np.int32))
+        else:        # new points, or the constructor's cv is still on the device: upload path + a MAX_SPEED reference
+            keep, self.cv = self.cv, np.full(m, MAX_SPEED)
+            self._bind(np.asarray(trajectory[:, :3], dtype=np.float64))
+            self.cv = keep
+        self._engine.set_speed_cutoff(np.array([cut], dtype=np.int32))
 
-    def step(self, state) -> Tuple[float, float]:
-        di, ai = super().step(state)
-        if self.status == 1:
-            self.ai = MAX_DECEL      # this module's MAX_DECEL (-5), main/lib/mpc_with_speed.py:300
-        return self.di, self.ai
+    def _failure_decel(self) -> float:
+        return MAX_DECEL      # this module's MAX_DECEL (-5), main/lib/mpc_with_speed.py:300
+
+    def is_goal(self, state) -> bool:
+        # main/lib/mpc_with_speed.py:313-330 with this module's GOAL_DIS / STOP_SPEED (0.5 / 3.6)
+        import math
+        d = math.hypot(state.x - self.goal[0], state.y - self.goal[1])
+        isgoal = d <= GOAL_DIS
+        if abs(self.target_ind - len(self.cx)) >= 5:
+            isgoal = False
+        return bool(isgoal and abs(state.v) <= STOP_SPEED)

@@ -70,12 +70,59 @@ def make_route(start_pos: int, turn: int, dl: float = DL, lane_offset: float = 3
     return np.stack([xr, yr, _wrap(yaw + rot)], axis=1)
 
 
+def _resample_uniform(x: np.ndarray, y: np.ndarray, dl: float) -> np.ndarray:
+    """Points at uniform arclength spacing dl along the polyline (x, y), yaw = direction of travel."""
+    seg = np.hypot(np.diff(x), np.diff(y))
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    M = int(math.floor(s[-1] / dl)) + 1
+    si = np.arange(M, dtype=np.float64) * dl
+    xi, yi = np.interp(si, s, x), np.interp(si, s, y)
+    h = 1e-3
+    yaw = np.arctan2(np.interp(si + h, s, y) - np.interp(si - h, s, y), np.interp(si + h, s, x) - np.interp(si - h, s, x))
+    return np.stack([xi, yi, yaw], axis=1)
+
+
+def make_multi_lane_route(start_pos: int, turn: int, start_lane: int, goal_lane: int, dl: float = DL) -> np.ndarray:
+    """One route of the reference's two-lane 4-arm intersection (main/envs/intersection_multi_lanes.py:9-60 with
+    number_of_lanes = 2, as main/scenarios/mpc_intersection_multi_lane.py:41-46 builds it): lane_width 4, median_width 2,
+    start / goal distance 30 -- lane centres 3 m and 7 m from the road axis.  Starts at (lane centre, -30) heading +y in the
+    canonical (south-arm) frame; left turns end heading -x at y = +goal lane centre, right turns heading +x at y = -goal lane
+    centre, straight routes change from the start lane to the goal lane with a smooth S-curve inside the junction.  Synthetic
+    stand-in for the planner's output (same [x, y, yaw] layout, spacing and extent; the planner needs the reference's pickled
+    motion primitives, which are never loaded)."""
+    lane_w, median, dist = 4.0, 2.0, 30.0
+    sx = median / 2 + (start_lane - 1) * lane_w + lane_w / 2
+    gl = (median + lane_w) / 2 + (goal_lane - 1) * lane_w
+    h = 0.01
+    if turn == 2:
+        y = np.arange(-dist, dist + h, h)
+        blend = np.clip((y + 10.0) / 20.0, 0.0, 1.0)
+        x = sx + (gl - sx) * 0.5 * (1.0 - np.cos(np.pi * blend))
+    else:
+        left = turn == 1
+        r = (8.0 + sx) if left else (2.0 + sx)
+        sgn = 1.0 if left else -1.0
+        y_end = gl if left else -gl
+        y_t = y_end - r
+        cxo = sx - sgn * r
+        th = np.arange(0.0, np.pi / 2, h / r)
+        y1 = np.arange(-dist, y_t, h)
+        x2 = np.arange(h, dist - abs(cxo) + h, h)
+        x = np.concatenate([np.full(len(y1), sx), cxo + sgn * r * np.cos(th), cxo - sgn * x2])
+        y = np.concatenate([y1, y_t + r * np.sin(th), np.full(len(x2), y_end)])
+    pts = _resample_uniform(x, y, dl)
+    rot = {1: 0.0, 2: -math.pi / 2, 3: math.pi, 4: math.pi / 2}[start_pos]
+    c, sn = math.cos(rot), math.sin(rot)
+    return np.stack([c * pts[:, 0] - sn * pts[:, 1], sn * pts[:, 0] + c * pts[:, 1], _wrap(pts[:, 2] + rot)], axis=1)
+
+
 def make_route_table(multi_lane: bool = False) -> List[np.ndarray]:
-    """The 12 routes (4 arms x 3 turns).  multi_lane=True shifts the lane offset (second lane of a
-    two-lane arm, lane width 3.5 m) to emulate mpc_intersection_multi_lane geometry."""
-    off = 3.0 + 3.5 if multi_lane else 3.0
-    arm = 40.0 if multi_lane else 30.0
-    return [make_route(sp, tn, lane_offset=off, arm=arm) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)]
+    """The 12 routes (4 arms x 3 turns) of the single-lane intersection, or with multi_lane=True the 48 routes
+    (4 arms x 3 turns x 2 start lanes x 2 goal lanes) of mpc_intersection_multi_lane's two-lane geometry."""
+    if multi_lane:
+        return [make_multi_lane_route(sp, tn, sl, gl) for sp in (1, 2, 3, 4) for tn in (1, 2, 3) for sl in (1, 2)
+                for gl in (1, 2)]
+    return [make_route(sp, tn, lane_offset=3.0, arm=30.0) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)]
 
 
 def smooth_yaw_inplace(yaw: np.ndarray) -> np.ndarray:

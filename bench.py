@@ -1,35 +1,59 @@
 #!/usr/bin/env python3
 """bench.py -- MPC receding-horizon steps/s of the HIP path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}]
 
-Workload (BASELINE.json configs[1]): 256 egos per GPU, kinematic bicycle, horizon T = 20, nu = 2, fp64,
-synthetic random-init egos on the 12 synthetic intersection routes, CLOSED LOOP: one "step" = one tick =
-one MPC.step for every ego (jsim_mpc_step) + the loop bookkeeping (plant update, history record, respawn
-of finished egos; jsim_loop_advance), all resident in HBM.  Weak scaling: every rank owns 256 egos, no
-collective on the solve path; the recorded controls are all-gathered once at the end (RCCL).
+`--gpus N` (N > 1) started plainly spawns its own N ranks (one per GPU, `python -m torch.distributed.run`, rendezvous on
+127.0.0.1) BEFORE this process imports torch or touches a GPU, relays their output and exits with their code; started
+under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+
+Workloads (BASELINE.json `configs`; synthetic random-init egos, everything resident in HBM, CLOSED LOOP: one "step" = one
+tick = one MPC.step for every ego + plant update + history + goal test / respawn, all K timed ticks in one fused launch):
+  --config 2 (default)  256 egos per GPU, horizon 20, fp64, the 12 synthetic intersection routes        [configs[1], the headline]
+  --config 3            4096 egos, horizon 30, the scenario loop with four scripted obstacle vehicles: obstacle prediction ->
+                        collision check -> path cut-off inside every tick (the reference's dynamic-obstacle mechanism)
+  --config 4            4096 egos per GPU (32768 / 8), horizon 20                                          [configs[3]]
+  --config 5            1024 egos per GPU (8192 / 8), horizon 40, multi-lane route geometry                [configs[4]]
+Weak scaling: every rank owns the same number of egos, no collective on the solve path; the recorded controls are
+all-gathered once at the end (RCCL all-gather; the job's only exchange).  With N > 1 and the default config the line also
+carries `extra`: the per-rank shares of configs 4 and 5 measured in the same job (same protocol).
 
 Prints ONE JSON line (rank 0).  `value` = egos x ticks / wall time (max over ranks).
-`roofline`  : the dominant kernel (mpc_step_kernel) against the fp64 peak -- the path is compute/latency
-              bound; `roofline_hbm` carries the algorithmic-bytes-vs-HBM figure BASELINE.json asks for.
-`cpu_baseline`: the CPU oracle (a C port of the reference path; the reference's cvxpy/ECOS stack cannot be
-              installed) timed on this box's host cores on the same synthetic batch.
+`roofline`     : the dominant kernel against the fp64 peak (the path is bound by single-wave fp64 issue latency, not by HBM
+                 and not by MFMA throughput: SURVEY D6); `roofline_hbm` carries the algorithmic-bytes-vs-HBM figure.
+`cpu_baseline` : the CPU oracle (a C port of the reference path; the reference's cvxpy/ECOS stack cannot be installed)
+                 running the same closed loop on this box's host cores, 1 core and all cores.
 """
 import argparse
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 matrix peak
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+
+# config -> (egos per GPU, horizon, route geometry, loop)
+CONFIGS = {
+    2: dict(batch=256, horizon=20, multi_lane=False, scenario=False,
+            name="BASELINE.json configs[1]: 256-ego batch, kinematic bicycle, horizon N=20, fp64"),
+    3: dict(batch=4096, horizon=30, multi_lane=False, scenario=True,
+            name="BASELINE.json configs[2]: 4096-ego batch, N=30, dynamic obstacles (four scripted vehicles: prediction, "
+                 "collision check and path cut-off inside every tick)"),
+    4: dict(batch=4096, horizon=20, multi_lane=False, scenario=False,
+            name="BASELINE.json configs[3]: 32768-ego batch over 8 GPUs = 4096 egos per GPU, N=20, fp64"),
+    5: dict(batch=1024, horizon=40, multi_lane=True, scenario=False,
+            name="BASELINE.json configs[4]: multi-lane geometry, 8192 egos over 8 GPUs = 1024 egos per GPU, N=40"),
+}
+OBSTACLE_SPECS = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None),
+                  dict(direction=-1, turning=True, speed=20 / 3.6, offset=6.0),
+                  dict(direction=1, turning=True, speed=15 / 3.6, offset=12.0),
+                  dict(direction=-1, turning=False, speed=25 / 3.6, offset=3.0)]
 
 
 def algorithmic_bytes_per_step(T, w=8):
@@ -42,31 +66,65 @@ def algorithmic_flops_per_step(T, n_iter):
     return 16 * T ** 3 + 8 * T ** 3 / 3 + 40 * T ** 2 * n_iter + 32 * T ** 2 + 60 * T
 
 
-def main():
+def kernel_name(T, scenario):
+    pre = "true" if scenario else "false"
+    if T in (13, 20, 30):
+        return f"mpc_step_reg_kernel<{T}, {pre}>"
+    if T == 40:
+        return f"mpc_step_reg2_kernel<{T}, {pre}>"
+    return "mpc_step_kernel"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=256, help="egos per GPU")
-    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2, help="BASELINE.json workload (see module docstring)")
+    ap.add_argument("--batch", type=int, default=0, help="egos per GPU (0: the config's)")
+    ap.add_argument("--horizon", type=int, default=0, help="horizon (0: the config's)")
     ap.add_argument("--mode", choices=("fused", "graph", "eager"), default="fused",
                     help="fused: K ticks per launch inside the kernel (default); graph: one launch pair per tick "
                          "replayed from a hipGraph; eager: one launch pair per tick from Python")
     ap.add_argument("--ticks-per-launch", type=int, default=0,
                     help="fused mode: closed-loop ticks per kernel launch (0 = all K ticks of the timed region in one launch; "
                          "egos only wait for each other at launch boundaries)")
+    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the config 4 / config 5 per-rank shares")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly: start the N ranks as a CHILD job.  Nothing in this process has imported
+    torch or initialised the GPU, and nothing is exec'ed: the parent only waits and hands the child's exit code on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import importlib
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     # JSIM_BENCH_REHEARSAL=1: all ranks share GPU 0 and the final gather runs over gloo -- lets the N>1 code path be
@@ -84,16 +142,7 @@ def main():
 
     pkg = importlib.import_module("av-simulation-at-intersections_amd")
     S = pkg.synth
-    T, B, K, W = args.horizon, args.batch, args.steps, args.warmup
-
-    routes = S.make_route_table()
-    for r in routes:
-        S.smooth_yaw_inplace(r[:, 2])
-    batch = S.make_ego_batch(routes, B, T, seed=1 + rank, truncate=False)
-    eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device=device, smooth=False)
-    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
-    x0 = torch.from_numpy(batch.x0).to(device)
-    loop = pkg.ClosedLoop(eng, x0, hist_cap=K + W + 8, max_age=400)
+    K, W = args.steps, args.warmup
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -101,160 +150,224 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # ---- warm-up (untimed)
-    for _ in range(W):
-        loop.tick()
-    torch.cuda.synchronize(device)
-    if world > 1:   # the job's one collective, run once untimed: communicator set-up and buffer registration are not the path
-        _ = pkg.sharding.gather_rows(loop.hist[:max(W, 1)].permute(1, 0, 2).contiguous(), B * world)
+    def run_workload(cfg_id, B, T, K, W, mode, tpl):
+        """W untimed ticks, then EXACTLY K timed ticks bracketed by barrier + synchronize; returns the figures of this rank
+        (elapsed = max over ranks)."""
+        cfg = CONFIGS[cfg_id]
+        routes = S.make_route_table(multi_lane=cfg["multi_lane"])
+        for r in routes:
+            S.smooth_yaw_inplace(r[:, 2])
+        batch = S.make_ego_batch(routes, B, T, seed=1 + rank, truncate=False)
+        eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device=device, smooth=False)
+        eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+        x0 = torch.from_numpy(batch.x0).to(device)
+        if cfg["scenario"]:
+            sc = pkg.ScenarioLoop(eng, x0, OBSTACLE_SPECS, hist_cap=K + W + 8, max_age=400)
+            loop, tick, run = sc.loop, sc.tick, sc.run
+            mode = "fused" if mode == "graph" else mode
+        else:
+            loop = pkg.ClosedLoop(eng, x0, hist_cap=K + W + 8, max_age=400)
+            tick, run = loop.tick, loop.run
+
+        for _ in range(W):          # warm-up (untimed)
+            tick()
         torch.cuda.synchronize(device)
+        if world > 1:   # the job's one collective, run once untimed: communicator set-up and buffer registration are not the path
+            _ = pkg.sharding.gather_rows(loop.hist[:max(W, 1)].permute(1, 0, 2).contiguous(), B * world)
+            torch.cuda.synchronize(device)
 
-    mode = args.mode
-    chunk = next(c for c in (50, 25, 20, 10, 5, 4, 2, 1) if K % c == 0)
-    if mode == "fused":
-        chunk = args.ticks_per_launch if args.ticks_per_launch > 0 else K
-        if K % chunk:
-            raise SystemExit(f"--ticks-per-launch {chunk} must divide --steps {K}")
-    if mode == "graph":
-        loop.capture(chunk)   # (capture runs one extra untimed tick)
-    elif mode == "fused":
-        loop.run(1)           # untimed: first use of the entry point
+        chunk = next(c for c in (50, 25, 20, 10, 5, 4, 2, 1) if K % c == 0)
+        if mode == "fused":
+            chunk = tpl if tpl > 0 else K
+            if K % chunk:
+                raise SystemExit(f"--ticks-per-launch {chunk} must divide --steps {K}")
+            run(1)                  # untimed: first use of the entry point
+        elif mode == "graph":
+            loop.capture(chunk)     # (capture runs one extra untimed tick)
 
-    # ---- timed region: exactly K ticks
-    n_iter_sum = torch.zeros((), dtype=torch.float64, device=device)
-    fused_evs = []
-    sync_all()
-    t0 = time.perf_counter()
-    if mode == "fused":       # closed loop on the device: `chunk` ticks per launch, egos never wait for each other
-        for _ in range(K // chunk):
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ea.record(); loop.run(chunk); eb.record()
-            fused_evs.append((ea, eb))
-    elif mode == "graph":
-        for _ in range(K // chunk):
-            loop.replay()
-    else:
-        for _ in range(K):
-            loop.tick()
-    if world > 1:   # the only exchange of the job: gather every rank's recorded controls (RCCL all-gather)
-        hist_local = loop.hist[:K].permute(1, 0, 2).contiguous()          # [B, K, 2]
-        hist_all = pkg.sharding.gather_rows(hist_local, B * world)
-        assert hist_all.shape[0] == B * world
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cpu" if rehearsal else device)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+        # ---- timed region: exactly K ticks.  HIP events are recorded on the stream the kernels are launched on (the
+        # engine passes torch's current stream of this device to the C-ABI, and torch.cuda.Event records on that stream)
+        evs = []
+        sync_all()
+        t0 = time.perf_counter()
+        if mode == "fused":         # closed loop on the device: `chunk` ticks per launch, egos never wait for each other
+            for _ in range(K // chunk):
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(); run(chunk); eb.record()
+                evs.append((ea, eb))
+        elif mode == "graph":
+            for _ in range(K // chunk):
+                loop.replay()
+        else:
+            for _ in range(K):
+                tick()
+        if world > 1:   # the only exchange of the job: gather every rank's recorded controls (RCCL all-gather)
+            hist_local = loop.hist[:K].permute(1, 0, 2).contiguous()          # [B, K, 2]
+            hist_all = pkg.sharding.gather_rows(hist_local, B * world)
+            assert hist_all.shape[0] == B * world
+        sync_all()
+        t1 = time.perf_counter()
+        elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cpu" if rehearsal else device)
+        if world > 1:
+            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        elapsed = float(elapsed.item())
 
-    # ---- dominant-kernel duration: HIP events on the launch stream around K more launches of mpc_step_kernel
-    # (same closed-loop states keep evolving; events bracket only the MPC kernel, not the bookkeeping kernel)
-    KE = min(K, 200)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KE)]
-    n_iter_sum.zero_()
-    ok_sum = 0
-    torch.cuda.synchronize(device)
-    for a, b in evs:
-        a.record()
-        eng.solve(loop.x0)
-        b.record()
-        n_iter_sum += eng.n_iter.sum()
-        _ = pkg._cabi.check(eng.lib.jsim_loop_advance(
-            eng._ctx, eng.B, loop.x0.data_ptr(), eng.oa.data_ptr(), eng.od.data_ptr(), eng.status.data_ptr(),
-            eng.di_ai.data_ptr(), eng.target_ind.data_ptr(), eng.path_id.data_ptr(), eng.path_len.data_ptr(),
-            loop.x0_spawn.data_ptr(), loop.target_spawn.data_ptr(), loop.age.data_ptr(), loop.max_age, None, None, 0,
-            loop.n_respawn.data_ptr(), eng._stream()), eng._ctx)
-    torch.cuda.synchronize(device)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))   # one single-tick launch
-    launches, ticks_per_launch = KE, 1
-    if mode == "fused":   # the dominant launch of the timed region IS the fused kernel: HIP events around each one
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in fused_evs]))
-        launches, ticks_per_launch = len(fused_evs), chunk
-    mean_iter = float(n_iter_sum.item()) / (KE * B)
-    n_fail = int((eng.status != 0).sum().item())
+        # ---- mean active-set iterations per step + (non-fused modes) the single-tick launch duration: KE more ticks,
+        # untimed for `value`, HIP events around the MPC kernel only
+        KE = min(K, 100)
+        sevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KE)]
+        n_iter_sum = torch.zeros((), dtype=torch.float64, device=device)
+        torch.cuda.synchronize(device)
+        if cfg["scenario"]:
+            for a, b in sevs:
+                a.record(); tick(); b.record()
+                n_iter_sum += eng.n_iter.sum()
+        else:
+            for a, b in sevs:
+                a.record(); eng.solve(loop.x0); b.record()
+                n_iter_sum += eng.n_iter.sum()
+                pkg._cabi.check(eng.lib.jsim_loop_advance(
+                    eng._ctx, eng.B, loop.x0.data_ptr(), eng.oa.data_ptr(), eng.od.data_ptr(), eng.status.data_ptr(),
+                    eng.di_ai.data_ptr(), eng.target_ind.data_ptr(), eng.path_id.data_ptr(), eng.path_len.data_ptr(),
+                    loop.x0_spawn.data_ptr(), loop.target_spawn.data_ptr(), loop.age.data_ptr(), loop.max_age, None, None, 0,
+                    loop.n_respawn.data_ptr(), eng._stream()), eng._ctx)
+        torch.cuda.synchronize(device)
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in sevs]))   # one single-tick launch
+        launches, ticks_per_launch = KE, 1
+        if mode == "fused":   # the dominant launch of the timed region IS the fused kernel: HIP events around each one
+            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            launches, ticks_per_launch = len(evs), chunk
+        mean_iter = float(n_iter_sum.item()) / (KE * B)
+        res = dict(cfg_id=cfg_id, B=B, T=T, K=K, W=W, mode=mode, chunk=chunk, elapsed=elapsed, kern_ms=kern_ms,
+                   launches=launches, ticks_per_launch=ticks_per_launch, mean_iter=mean_iter,
+                   n_fail=int((eng.status != 0).sum().item()), respawns=int(loop.n_respawn.item()),
+                   value=B * world * K / elapsed, routes=routes, batch=batch,
+                   cut=int((eng.path_len < eng.full_len).sum().item()) if cfg["scenario"] else None)
+        eng.close()
+        return res
 
-    steps_total = B * world * K
-    value = steps_total / elapsed
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg["batch"]
+    T = args.horizon or cfg["horizon"]
+    main_res = run_workload(args.config, B, T, K, W, args.mode, args.ticks_per_launch)
+    extra = {}
+    if world > 1 and args.config == 2 and not args.no_extra and not (args.batch or args.horizon):
+        for cid in (4, 5):   # the named multi-GPU configurations' per-rank shares, same job, same protocol, fewer ticks
+            c = CONFIGS[cid]
+            Ke = max(10, min(K, 100 if cid == 4 else 40))
+            r = run_workload(cid, c["batch"], c["horizon"], Ke, min(W, 5), "fused", 0)
+            extra[f"config{cid}"] = {"workload": c["name"], "value": r["value"], "unit": "MPC steps/s", "egos_total": c["batch"] * world,
+                                     "horizon": c["horizon"], "steps": Ke, "ms_per_step": r["elapsed"] / Ke * 1e3,
+                                     "mean_active_set_iters": round(r["mean_iter"], 2), "failed_egos_last_tick": r["n_fail"]}
 
     if rank == 0:
-        flops = algorithmic_flops_per_step(T, mean_iter) * B * ticks_per_launch
-        nbytes = algorithmic_bytes_per_step(T) * B * ticks_per_launch
-        ach_tf = flops / (kern_ms * 1e-3) / 1e12
-        ach_gbs = nbytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(REPO, "profiles", "r01_bench_fused_pmc_summary.json")
-        if mode == "fused" and T == 20 and B == 256 and os.path.exists(pmc_path):
-            # HBM bytes of one fused launch from the rocprofv3 PMC passes of this same command (profiles/r01_SUMMARY.txt):
-            # FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request), WRITE_SIZE as is, both in KiB; scaled to this chunk
+        r = main_res
+        tpl = r["ticks_per_launch"]
+        flops = algorithmic_flops_per_step(T, r["mean_iter"]) * B * tpl
+        nbytes = algorithmic_bytes_per_step(T) * B * tpl
+        ach_tf = flops / (r["kern_ms"] * 1e-3) / 1e12
+        ach_gbs = nbytes / (r["kern_ms"] * 1e-3) / 1e9
+        traffic, traffic_source = None, "not measured in this run (PMC counters need their own rocprofv3 passes)"
+        pmc_path = os.path.join(REPO, "profiles", f"r02_config{args.config}_pmc_summary.json")
+        if r["mode"] == "fused" and (B, T) == (cfg["batch"], cfg["horizon"]) and os.path.exists(pmc_path):
+            # HBM bytes of one fused launch from the rocprofv3 PMC passes of this same command, collected in a SEPARATE run
+            # (tools/collect_profile.sh): FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request), WRITE_SIZE as is,
+            # both in KiB; scaled to this launch's tick count
             pmc = json.load(open(pmc_path))
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (ticks_per_launch / float(pmc.get("ticks_per_launch", 50)))
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (tpl / float(pmc.get("ticks_per_launch", 100)))
+                traffic_source = (f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc passes of this command "
+                                  f"({pmc.get('ticks_per_launch', 100)} ticks per launch), scaled to {tpl} ticks; stale if the kernel changed since")
+        waves = 2 if T == 40 else 1
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",
-            "value": value, "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": r["value"], "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": r["elapsed"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{B}-ego batch per GPU, kinematic bicycle, horizon N={T}, nu=2, fp64, closed loop "
-                                   f"({'BASELINE.json configs[1]' if (B, T) == (256, 20) else 'not the headline config'})", "egos_per_gpu": B, "horizon": T,
-                       "launch": {"fused": f"fused closed loop, {chunk} ticks per launch", "graph": "hipGraph",
-                                  "eager": "eager"}[mode], "parallelism": f"ego-shard x{world}",
-                       "mean_active_set_iters": round(mean_iter, 2), "failed_egos_last_tick": n_fail,
-                       "respawns": int(loop.n_respawn.item())},
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": (f"mpc_step_reg_kernel<{T}, false>" if T in (13, 20, 30) else
-                                    f"mpc_step_reg2_kernel<{T}, false>" if T == 40 else "mpc_step_kernel"), "kernel_ms": kern_ms,
-                         "ticks_per_launch": ticks_per_launch,
-                         "algorithmic_flops_per_launch": flops,
-                         "note": ("fp64 vector/matrix peak; latency-bound: " +
-                                  (f"{2 if T == 40 else 1} wave(s) per ego, {B} egos on 256 CUs (1024 SIMDs)"))},
+            "config": {"workload": f"{B} egos per GPU, horizon N={T}, nu=2, fp64, closed loop -- "
+                                   + (cfg["name"] if (B, T) == (cfg["batch"], cfg["horizon"]) else "not a named configuration"),
+                       "baseline_config": args.config, "egos_per_gpu": B, "egos_total": B * world, "horizon": T,
+                       "routes": "multi-lane synthetic" if cfg["multi_lane"] else "synthetic 4-arm intersection, 12 routes",
+                       "launch": {"fused": f"fused closed loop, {r['chunk']} ticks per launch", "graph": "hipGraph",
+                                  "eager": "eager"}[r["mode"]], "parallelism": f"ego-shard x{world}",
+                       "mean_active_set_iters": round(r["mean_iter"], 2), "failed_egos_last_tick": r["n_fail"],
+                       "respawns": r["respawns"]},
+            "roofline": {"bound": "issue-latency", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name(T, cfg["scenario"]), "kernel_ms": r["kern_ms"],
+                         "ticks_per_launch": tpl, "algorithmic_flops_per_launch": flops,
+                         "note": ("priced against the fp64 vector = matrix peak; the kernel is bound by the issue latency of "
+                                  f"{waves} wave(s) per ego ({B} egos on 256 CUs / 1024 SIMDs), not by HBM (roofline_hbm) "
+                                  "and not by MFMA throughput (the MFMA pipe is < 1 % busy)")},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes},
         }
+        if cfg["scenario"]:
+            out["config"]["obstacle_vehicles"] = len(OBSTACLE_SPECS)
+            out["config"]["egos_cut_off_last_tick"] = r["cut"]
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, routes, batch, T, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pkg, r["routes"], r["batch"], T, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def host_cpu_description():
+    model, threads = "?", os.cpu_count() or 1
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in txt.splitlines():
+            if line.startswith("Model name:"):
+                model = line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return model, threads
+
+
 def cpu_baseline(pkg, routes, batch, T, seconds):
-    """The oracle (C port of the reference path) on the host cores, same synthetic batch (tick 0)."""
+    """The oracle (C port of the reference path) running the SAME closed loop on the host cores: MPC.step with the carried
+    warm start -> Simulation.step -> goal test / respawn (oracle/mpc_oracle.c orc_closed_loop), OpenMP over egos, on every
+    core this process may run on; a bounded sample (~`seconds` s)."""
+    import numpy as np
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_py as O
     O.build()
     p = O.make_params(T=T)
     cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
-    cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
-        pass
-    cores = max(1, min(cores, 16))   # the GPU box's CPU share for one GPU is 16 cores
-    # tile the batch so that every thread has real work (256 egos over 16 threads would be one malloc-bound
-    # scheduling quantum each)
-    rep = 8
-    tile = lambda a: np.concatenate([a] * rep, axis=0)
-    big = pkg.synth.EgoBatch(x0=tile(batch.x0), path_id=tile(batch.path_id), path_len=tile(batch.path_len),
-                             target_ind=tile(batch.target_ind), speed=tile(batch.speed), oa=tile(batch.oa),
-                             od=tile(batch.od))
+        cores = os.cpu_count() or 1
+    cores = max(1, cores)
+    model, hw_threads = host_cpu_description()
     B = batch.x0.shape[0]
 
-    def run(bt, nthreads, budget):
+    def take(n):   # the first n egos of the batch, tiled when n > B
+        idx = np.arange(n) % B
+        sub = pkg.synth.EgoBatch(x0=batch.x0[idx], path_id=batch.path_id[idx], path_len=batch.path_len[idx],
+                                 target_ind=batch.target_ind[idx], speed=batch.speed[idx], oa=batch.oa[idx], od=batch.od[idx])
+        return O.loop_state_from_batch(sub, T)
+
+    def run(n_egos, nthreads, budget, ticks_per_call):
+        st = take(n_egos)
         n, t0 = 0, time.perf_counter()
         while True:
-            O.mpc_step_batch(p, bt.x0, bt.path_id, bt.path_len, bt.speed, cx, cy, cyaw, off, bt.target_ind, bt.oa,
-                             bt.od, n_threads=nthreads)
-            n += bt.x0.shape[0]
+            O.closed_loop(p, st, cx, cy, cyaw, off, ticks_per_call, max_age=400, n_threads=nthreads, record=False)
+            n += n_egos * ticks_per_call
             dt = time.perf_counter() - t0
             if dt >= budget:
-                return n / dt
-    one = run(batch, 1, seconds * 0.4)
-    allc = run(big, cores, seconds * 0.6)
+                return n / dt, n
+    one, n1 = run(min(B, 32), 1, seconds * 0.35, 2)
+    n_all = max(B, 8 * cores)       # every thread gets whole egos to loop over
+    allc, na = run(n_all, cores, seconds * 0.65, 4)
     return {"value": allc, "unit": "MPC steps/s", "cores": cores, "kind": "port",
-            "value_1core": one,
-            "sample": f"tick-0 batch of {B} egos (T={T}; x{rep} tiled for the {cores}-thread run) re-solved for ~{seconds:.0f} s: C port of the reference path "
-                      f"(oracle/mpc_oracle.c, exact active-set QP), OpenMP over egos; cvxpy/ECOS unavailable offline"}
+            "value_1core": one, "host_cpu": model, "host_hw_threads": hw_threads,
+            "sample": (f"closed loop (MPC.step with carried warm start -> plant -> goal/respawn) of the same synthetic egos at T={T}: "
+                       f"{n1} steps of {min(B, 32)} egos on 1 core, {na} steps of {n_all} egos on {cores} cores (OpenMP over egos); "
+                       "C port of the reference path (oracle/mpc_oracle.c, exact active-set QP); cvxpy/ECOS unavailable offline")}
 
 
 if __name__ == "__main__":

@@ -817,3 +817,77 @@ int orc_is_goal(const orc_params *p, double sx, double sy, double sv, double goa
     int isstop = fabs(sv) <= p->stop_speed;
     return isgoal && isstop;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * main/scenarios/mpc_intersection.py:99-163 -- the per-vehicle loop for B independent egos, n_ticks ticks each:
+ * MPC.step (warm start carried, failure path ai = MAX_DECEL / di kept, mpc.py:298-303) -> Simulation.step
+ * (lib/simulation.py:35-47) -> `if mpc.is_goal(state): break` (:101), a finished ego (or one older than max_age
+ * ticks) restarting from its spawn state with a cold controller -- the bookkeeping of the product's
+ * jsim_loop_advance.  hist [n_ticks][B][2] = applied (di, ai) (NULL: not recorded).  OpenMP over egos: each thread
+ * runs whole egos (every tick of an ego depends on its previous one).  Used as the closed-loop checker of
+ * jsim_mpc_run_ticks and as bench.py's cpu_baseline.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_closed_loop(const orc_params *p, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id,
+                    const int32_t *path_len, const double *speed, const double *cx, const double *cy,
+                    const double *cyaw, const int64_t *path_off, int64_t *target_ind, double *oa, double *od,
+                    double *di_ai, const double *x0_spawn, const int64_t *target_spawn, int32_t *age,
+                    int32_t max_age, double *hist, int64_t *n_respawn, int64_t *n_iter_sum, int64_t *n_fail,
+                    int32_t n_threads)
+{
+    const int T = p->T, W = T + 1;
+    int64_t resp = 0, iters = 0, fails = 0;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : resp, iters, fails)
+#endif
+    for (int32_t b = 0; b < B; ++b) {
+        const int64_t off = path_off[path_id[b]];
+        const int64_t full = path_off[path_id[b] + 1] - off;
+        double *tmp = (double *)malloc(sizeof(double) * (2 * T + 4 * W));
+        double *woa = &oa[(size_t)b * T], *wod = &od[(size_t)b * T];
+        double st4[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
+        for (int32_t k = 0; k < n_ticks; ++k) {
+            orc_step_out o;
+            memset(&o, 0, sizeof(o));
+            o.oa = tmp; o.od = tmp + T; o.ox = tmp + 2 * T; o.oy = o.ox + W; o.ov = o.oy + W; o.oyaw = o.ov + W;
+            int st = orc_mpc_step_cv(p, st4[0], st4[1], st4[3], st4[2], cx + off, cy + off, cyaw + off, NULL, -1,
+                                     (int64_t)path_len[b], target_ind[b], speed[b], woa, wod, &o);
+            iters += o.n_iter;
+            if (st != ORC_NEAREST_ANOMALY) target_ind[b] = o.target_ind;
+            double di = di_ai[2 * b], ai;
+            if (st == ORC_OK) {
+                memcpy(woa, o.oa, sizeof(double) * T);
+                memcpy(wod, o.od, sizeof(double) * T);
+                di = wod[0];
+                ai = woa[0];
+            } else {
+                ++fails;
+                if (st == ORC_INFEASIBLE) { memset(woa, 0, sizeof(double) * T); memset(wod, 0, sizeof(double) * T); }
+                ai = p->max_decel;
+            }
+            di_ai[2 * b] = di;
+            di_ai[2 * b + 1] = ai;
+            if (hist) { hist[((size_t)k * B + b) * 2] = di; hist[((size_t)k * B + b) * 2 + 1] = ai; }
+            orc_plant_step(p, st4, ai, di);
+            const int goal = orc_is_goal(p, st4[0], st4[1], st4[2], cx[off + full - 1], cy[off + full - 1], target_ind[b],
+                                         (int64_t)path_len[b]);
+            if (goal || (max_age > 0 && age[b] + 1 >= max_age)) {
+                for (int r = 0; r < 4; ++r) st4[r] = x0_spawn[4 * b + r];
+                target_ind[b] = target_spawn[b];
+                memset(woa, 0, sizeof(double) * T);
+                memset(wod, 0, sizeof(double) * T);
+                di_ai[2 * b] = 0.0; di_ai[2 * b + 1] = 0.0;
+                age[b] = 0;
+                ++resp;
+            } else {
+                age[b] += 1;
+            }
+        }
+        for (int r = 0; r < 4; ++r) x0[4 * b + r] = st4[r];
+        free(tmp);
+    }
+    if (n_respawn) *n_respawn += resp;
+    if (n_iter_sum) *n_iter_sum += iters;
+    if (n_fail) *n_fail += fails;
+    return ORC_OK;
+}

@@ -192,6 +192,16 @@ double orc_xref_deviation(const double *cx, const double *cy, const double *cyaw
 int orc_is_goal(const orc_params *p, double sx, double sy, double sv, double goal_x, double goal_y,
                 int64_t target_ind, int64_t ncourse);
 
+/* n_ticks ticks of the per-vehicle loop (main/scenarios/mpc_intersection.py:99-163) for B independent egos: MPC.step with the
+ * carried warm start -> Simulation.step -> goal test / respawn, OpenMP over egos.  All state arrays in/out (layouts of the
+ * batched step; di_ai [B][2], age [B]); hist [n_ticks][B][2] may be NULL; the three counters are incremented. */
+int orc_closed_loop(const orc_params *p, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id,
+                    const int32_t *path_len, const double *speed, const double *cx, const double *cy,
+                    const double *cyaw, const int64_t *path_off, int64_t *target_ind, double *oa, double *od,
+                    double *di_ai, const double *x0_spawn, const int64_t *target_spawn, int32_t *age,
+                    int32_t max_age, double *hist, int64_t *n_respawn, int64_t *n_iter_sum, int64_t *n_fail,
+                    int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

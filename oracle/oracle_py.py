@@ -141,6 +141,8 @@ def lib() -> C.CDLL:
         L.orc_mpc_step_cv.argtypes = [C.POINTER(OrcParams)] + [C.c_double] * 4 + [dp, dp, dp, C.c_void_p, C.c_int64,
                                       C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(OrcStepOut)]
         L.orc_mpc_step_cv.restype = C.c_int
+        L.orc_closed_loop.argtypes = [C.POINTER(OrcParams), C.c_int32, C.c_int32] + [C.c_void_p] * 15 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32]
+        L.orc_closed_loop.restype = C.c_int
         L.orc_xref_deviation.argtypes = [dp, dp, dp, C.c_int64, C.c_double, C.c_double]
         L.orc_xref_deviation.restype = C.c_double
         L.orc_is_goal.argtypes = [C.POINTER(OrcParams)] + [C.c_double] * 5 + [C.c_int64, C.c_int64]
@@ -276,6 +278,38 @@ def mpc_step_batch(p, x0, path_id, path_len, speed, cx, cy, cyaw, path_off, targ
                              ptr(out["oyaw"]), ptr(out["xref"]), ptr(out["active_mask"]),
                              ptr(out["status"]), ptr(out["n_iter"]), int(n_threads))
     return out
+
+
+def closed_loop(p, state, cx, cy, cyaw, path_off, n_ticks, max_age=0, n_threads=1, record=True):
+    """n_ticks closed-loop ticks (MPC.step -> plant -> goal / respawn) for every ego, IN PLACE on `state`, a dict of C-contiguous
+    arrays: x0 [B,4], path_id, path_len (int32), speed, target_ind (int64), oa, od [B,T], di_ai [B,2], x0_spawn, target_spawn,
+    age (int32).  Returns {"hist": [n_ticks,B,2] or None, "n_respawn", "n_iter_sum", "n_fail"}."""
+    B = state["x0"].shape[0]
+    hist = np.zeros((n_ticks, B, 2)) if record else None
+    cnt = np.zeros(3, dtype=np.int64)
+    cx, cy, cyaw = _c(cx), _c(cy), _c(cyaw); path_off = _c(path_off, np.int64)
+    for k, dt in (("x0", np.float64), ("path_id", np.int32), ("path_len", np.int32), ("speed", np.float64),
+                  ("target_ind", np.int64), ("oa", np.float64), ("od", np.float64), ("di_ai", np.float64),
+                  ("x0_spawn", np.float64), ("target_spawn", np.int64), ("age", np.int32)):
+        a = state[k]
+        if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous):
+            raise ValueError(f"state[{k!r}] must be a C-contiguous {dt.__name__} array (it is updated in place)")
+    ptr = lambda a: None if a is None else a.ctypes.data
+    lib().orc_closed_loop(C.byref(p), B, int(n_ticks), ptr(state["x0"]), ptr(state["path_id"]), ptr(state["path_len"]),
+                          ptr(state["speed"]), ptr(cx), ptr(cy), ptr(cyaw), ptr(path_off), ptr(state["target_ind"]),
+                          ptr(state["oa"]), ptr(state["od"]), ptr(state["di_ai"]), ptr(state["x0_spawn"]),
+                          ptr(state["target_spawn"]), ptr(state["age"]), int(max_age), ptr(hist),
+                          cnt[0:].ctypes.data, cnt[1:].ctypes.data, cnt[2:].ctypes.data, int(n_threads))
+    return {"hist": hist, "n_respawn": int(cnt[0]), "n_iter_sum": int(cnt[1]), "n_fail": int(cnt[2])}
+
+
+def loop_state_from_batch(batch, T):
+    """Fresh closed-loop state dict (see closed_loop) from a synth.EgoBatch."""
+    B = batch.x0.shape[0]
+    return {"x0": _c(batch.x0).copy(), "path_id": _c(batch.path_id, np.int32).copy(), "path_len": _c(batch.path_len, np.int32).copy(),
+            "speed": _c(batch.speed).copy(), "target_ind": _c(batch.target_ind, np.int64).copy(), "oa": _c(batch.oa).copy(),
+            "od": _c(batch.od).copy(), "di_ai": np.zeros((B, 2)), "x0_spawn": _c(batch.x0).copy(),
+            "target_spawn": _c(batch.target_ind, np.int64).copy(), "age": np.zeros(B, dtype=np.int32)}
 
 
 def xref_deviation(cx, cy, cyaw, target_ind, ox0, oy0):

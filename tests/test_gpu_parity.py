@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from conftest import load_golden
+from gpu_helpers import kkt_check
 
 pytestmark = pytest.mark.gpu
 TS = (13, 20, 30, 40)
@@ -117,42 +118,7 @@ def test_kkt_property_at_full_size(pkg, routes):
         torch.cuda.synchronize()
         st = eng.status
         assert int((st == 0).sum()) >= B - 2
-        ok = st == 0
-        H = dbg["H"]; H = torch.tril(H) + torch.tril(H, -1).transpose(1, 2)
-        u = torch.stack([eng.oa, eng.od], dim=2).reshape(B, 2 * T)
-        lam = dbg["lam"]
-        n, m = 2 * T, 8 * T
-        # G rows from the structure (canonical order), built once
-        G = torch.zeros(m, n, dtype=torch.float64, device=eng.device)
-        for t in range(T - 1):
-            G[2 * t, 2 * t + 3] = 1; G[2 * t, 2 * t + 1] = -1; G[2 * t + 1] = -G[2 * t]
-        for t in range(T + 1):
-            G[2 * T - 2 + t, 0:2 * t:2] = eng.dt
-            G[3 * T - 1 + t] = -G[2 * T - 2 + t]
-        for t in range(T):
-            G[4 * T + t, 2 * t] = 1; G[5 * T + t, 2 * t] = -1
-            G[6 * T + 2 * t, 2 * t + 1] = 1; G[6 * T + 2 * t + 1, 2 * t + 1] = -1
-        c = eng.config
-        h = torch.zeros(B, m, dtype=torch.float64, device=eng.device)
-        x0 = torch.from_numpy(batch.x0).to(eng.device)
-        h[:, :2 * T - 2] = c.max_dsteer_rad * eng.dt
-        h[:, 2 * T - 2:3 * T - 1] = (eng.speed - x0[:, 2])[:, None]
-        h[:, 3 * T - 1:4 * T] = (x0[:, 2] - c.MIN_SPEED)[:, None]
-        h[:, 4 * T:5 * T] = c.MAX_ACCEL
-        h[:, 5 * T:6 * T] = -c.MAX_DECEL
-        h[:, 6 * T:] = c.MAX_STEER_RAD
-        stat = torch.einsum("bij,bj->bi", H, u) + dbg["g"] + lam @ G
-        scale = dbg["g"].abs().amax(dim=1).clamp(min=1.0)
-        assert float((stat.abs().amax(dim=1) / scale)[ok].max()) <= 1e-8
-        slack = h - u @ G.T
-        assert float((-slack)[ok].max()) <= 1e-8                       # primal feasible
-        assert float(lam[ok].min()) >= 0.0                             # dual feasible
-        assert float((lam * slack).abs()[ok].max() / float(scale.max())) <= 1e-8   # complementary
-        # active bits <=> positive multipliers
-        words = eng.active_mask.cpu().numpy().view(np.uint32)
-        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, -1)[:, :m].astype(bool)
-        thr = (1e-9 * scale).cpu().numpy()[:, None]
-        assert np.array_equal(bits[ok.cpu().numpy()], (lam.cpu().numpy() > thr)[ok.cpu().numpy()])
+        kkt_check(eng, batch, dbg)
 
 
 def test_empty_batch_and_bad_args(pkg, routes):

@@ -402,3 +402,46 @@ def test_jerk_dropin_closed_loop(pkg, oracle, routes):
         tind, oa, od = ref["target_ind"], ref["oa"], ref["od"]
         state = oracle.plant_step(p, state, ref["oa"][0], ref["od"][0])
     assert state[2] > 1.0                                          # it drove off
+
+
+@pytest.mark.gpu
+def test_with_speed_dropin_resets_the_constructor_reference(pkg, oracle, routes):
+    """main/lib/mpc_with_speed.py:276-282: EVERY set_trajectory_fromarray rebuilds cv = MAX_SPEED (and zeroes it from
+    cutoff_idx on, a negative index counting from the end like any Python slice) -- also when the constructor was given
+    another speed reference and the trajectory is a prefix of the bound path; is_goal uses this module's STOP_SPEED."""
+    m = pkg.mpc_with_speed
+    r = routes[3].copy()
+    cv0 = np.linspace(2.0, 6.0, len(r))                         # a constructor reference that is NOT MAX_SPEED
+    mpc = m.MPC(cx=r[:, 0], cy=r[:, 1], cv=cv0, cyaw=r[:, 2].copy(), dl=pkg.synth.DL, car_dimensions=pkg.BicycleModelDimensions())
+    p = _variant_params(oracle)
+    st = pkg.State(x=r[80, 0], y=r[80, 1], yaw=r[80, 2], v=4.0)
+    # 1. before any set_trajectory_fromarray the constructor's cv is the reference
+    mpc.target_ind = 76
+    mpc.step(st)
+    ref0 = oracle.mpc_step(p, (st.x, st.y, st.yaw, st.v), r[:, 0], r[:, 1], r[:, 2], 76, 30 / 3.6, cv=cv0)
+    assert np.array_equal(mpc.xref, ref0["xref"]) and float(mpc.xref[2].max()) < 6.0
+    # 2. a prefix of the bound path: the reference becomes MAX_SPEED, zero over the last 40 points (cutoff_idx = -40)
+    n = 400
+    mpc.oa = mpc.odelta = None
+    mpc.target_ind = 76
+    mpc.set_trajectory_fromarray(r[:n], cutoff_idx=-40)
+    assert np.all(mpc.cv[:n - 40] == m.MAX_SPEED) and np.all(mpc.cv[n - 40:] == 0) and len(mpc.cv) == n
+    mpc.step(st)
+    cv1 = np.full(n, m.MAX_SPEED); cv1[-40:] = 0
+    ref1 = oracle.mpc_step(p, (st.x, st.y, st.yaw, st.v), r[:n, 0], r[:n, 1], r[:n, 2], 76, 30 / 3.6, cv=cv1)
+    assert mpc.status == ref1["status"] == 0
+    assert np.array_equal(mpc.xref, ref1["xref"]) and float(mpc.xref[2].max()) == m.MAX_SPEED
+    np.testing.assert_allclose(np.concatenate([mpc.oa, mpc.odelta]), np.concatenate([ref1["oa"], ref1["od"]]), rtol=0, atol=1e-8)
+    # 3. near the cut: part of the window has a zero speed reference
+    st2 = pkg.State(x=r[345, 0], y=r[345, 1], yaw=r[345, 2], v=5.0)
+    mpc.oa = mpc.odelta = None
+    mpc.target_ind = 340
+    mpc.set_trajectory_fromarray(r[:n], cutoff_idx=-40)
+    mpc.step(st2)
+    ref2 = oracle.mpc_step(p, (st2.x, st2.y, st2.yaw, st2.v), r[:n, 0], r[:n, 1], r[:n, 2], 340, 30 / 3.6, cv=cv1)
+    assert np.array_equal(mpc.xref, ref2["xref"]) and (mpc.xref[2] == 0).any() and (mpc.xref[2] > 0).any()
+    # 4. the goal test stops at this module's 0.5 / 3.6, not lib.mpc's 0.1389
+    mpc.target_ind = len(mpc.cx) - 2
+    g = pkg.State(x=mpc.goal[0], y=mpc.goal[1], yaw=0.0, v=0.1389)
+    assert m.STOP_SPEED < 0.1389 and not mpc.is_goal(g)
+    assert mpc.is_goal(pkg.State(x=mpc.goal[0], y=mpc.goal[1], yaw=0.0, v=0.13))
