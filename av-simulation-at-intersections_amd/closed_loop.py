@@ -203,6 +203,11 @@ class ScriptedObstacles:
         self.state = torch.tensor(st, dtype=torch.float64, device=dev).reshape(self.n, 4)
         self.param = torch.tensor(pr, dtype=torch.float64, device=dev).reshape(self.n, 8)
         self.get_buf = torch.zeros(max(self.n, 1), 6, dtype=torch.float64, device=dev)
+        self._state0 = self.state.clone()
+
+    def reset(self):
+        """Send the vehicles in again from their start poses (asynchronous device copy on the current stream)."""
+        self.state.copy_(self._state0)
 
     def get(self, step: bool = False) -> torch.Tensor:
         """The `o.get()` tuples of all obstacles ([n, 6] device tensor); step=True also applies `o.step()` afterwards."""
