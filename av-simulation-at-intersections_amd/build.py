@@ -30,13 +30,15 @@ def _hipcc() -> str:
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
-    deps = [SRC, os.path.join(_HERE, "csrc", "mpc_step_reg.inc"), os.path.join(_HERE, "csrc", "mpc_step_reg2.inc"), os.path.join(_HERE, "csrc", "loop_pre_tick.inc"), os.path.join(INC, "jsim_mpc.h")]
+    csrc = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))] + [os.path.join(INC, "jsim_mpc.h")]
     return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, SRC, "-o", LIB]
+        extra = os.environ.get("JSIM_HIPCC_EXTRA", "").split()   # diagnostic builds (-DJSIM_STAMPS, -DJSIM_DEV_ONLY_T40, ...)
+        cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", INC, SRC, "-o", os.environ.get("JSIM_LIB_OUT", LIB)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 
 #include "mpc_step_reg.inc"
 #include "mpc_step_reg2.inc"
+#include "mpc_step_reg4.inc"
 
 // horizons with a register-resident kernel: 3T+1 <= 64 lanes -> one wavefront per ego; T = 30 / 40 -> two wavefronts per ego
 #ifndef JSIM_REG2_T_A
@@ -1073,11 +1074,22 @@ static bool has_fused_glue(int T) { return has_reg_kernel(T); }
 static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
 {
     static const PreK none = {};
-    if (Q) { // the loop glue inside the launch (one-wave kernels only)
+#ifdef JSIM_DEV_ONLY_T40 /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
+    if (T == 40) {
+        if (Q) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
+        else hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
+    }
+    return;
+#else
+    if (Q) { // the loop glue inside the launch
         if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+#ifdef JSIM_T40_TWO_WAVE
         else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_B, true>), dim3(B), dim3(128), 0, s, P, K, *Q);
+#else
+        else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
+#endif
         return;
     }
     if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false>), dim3(B), dim3(64), 0, s, P, K, none);
@@ -1087,8 +1099,11 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
 #else
     else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
 #endif
-#if JSIM_REG2_T_B != JSIM_REG2_T_A
+#ifdef JSIM_T40_TWO_WAVE
     else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_B, false>), dim3(B), dim3(128), 0, s, P, K, none);
+#else
+    else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
+#endif
 #endif
 }
 
