@@ -18,8 +18,9 @@ pkg = importlib.import_module("av-simulation-at-intersections_amd")
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-lib = os.path.join(REPO, "av-simulation-at-intersections_amd", "libjsim_mpc_stamps.so")
-subprocess.check_call([pkg.build._hipcc()] + pkg.build.HIPCC_FLAGS + ["-DJSIM_STAMPS", "-I", pkg.build.INC, pkg.build.SRC, "-o", lib])
+lib = os.environ.get("JSIM_STAMPS_LIB") or os.path.join(REPO, "av-simulation-at-intersections_amd", "libjsim_mpc_stamps.so")
+if not os.environ.get("JSIM_STAMPS_LIB"):   # (JSIM_STAMPS_LIB: a -DJSIM_STAMPS library built beforehand)
+    subprocess.check_call([pkg.build._hipcc()] + pkg.build.HIPCC_FLAGS + ["-DJSIM_STAMPS", "-I", pkg.build.INC, pkg.build.SRC, "-o", lib])
 pkg._cabi.LIB_PATH = lib
 pkg._cabi._lib = None
 S = pkg.synth

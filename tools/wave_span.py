@@ -17,12 +17,13 @@ pkg = importlib.import_module("av-simulation-at-intersections_amd")
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-lib = os.path.join(REPO, "av-simulation-at-intersections_amd", "libjsim_mpc_span.so")
-subprocess.check_call([pkg.build._hipcc()] + pkg.build.HIPCC_FLAGS + ["-DJSIM_SPAN", "-I", pkg.build.INC, pkg.build.SRC, "-o", lib])
+lib = os.environ.get("JSIM_SPAN_LIB") or os.path.join(REPO, "av-simulation-at-intersections_amd", "libjsim_mpc_span.so")
+if not os.environ.get("JSIM_SPAN_LIB"):   # (JSIM_SPAN_LIB: a -DJSIM_SPAN library built beforehand, e.g. where there is no GPU)
+    subprocess.check_call([pkg.build._hipcc()] + pkg.build.HIPCC_FLAGS + ["-DJSIM_SPAN", "-I", pkg.build.INC, pkg.build.SRC, "-o", lib])
 pkg._cabi.LIB_PATH = lib
 pkg._cabi._lib = None
 S = pkg.synth
-routes = S.make_route_table()
+routes = S.make_route_table(multi_lane=os.environ.get("JSIM_MULTI_LANE") == "1")
 for r in routes:
     S.smooth_yaw_inplace(r[:, 2])
 batch = S.make_ego_batch(routes, B, T, seed=1)
