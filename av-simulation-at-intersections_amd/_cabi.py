@@ -35,6 +35,7 @@ EXPORTS = (
     "jsim_loop_set_geometry", "jsim_loop_set_obstacle_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
     "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_mpc_set_ego_config", "jsim_loop_obstacles",
     "jsim_mpc_xref_deviation_goal", "jsim_loop_run_scenario",
+    "jsim_comm_unique_id", "jsim_comm_init", "jsim_mpc_gather", "jsim_comm_destroy",
 )
 
 _lib = None
@@ -100,6 +101,14 @@ def load() -> C.CDLL:
                                            [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, vp])
     lib.jsim_mpc_xref_deviation_goal.restype = C.c_int
     lib.jsim_mpc_xref_deviation_goal.argtypes = [vp, i32] + [vp] * 9
+    lib.jsim_comm_unique_id.restype = C.c_int
+    lib.jsim_comm_unique_id.argtypes = [vp]
+    lib.jsim_comm_init.restype = C.c_int
+    lib.jsim_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.jsim_mpc_gather.restype = C.c_int
+    lib.jsim_mpc_gather.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+    lib.jsim_comm_destroy.restype = C.c_int
+    lib.jsim_comm_destroy.argtypes = [vp]
     if lib.jsim_abi_version() != ABI_VERSION:
         raise JsimError(f"libjsim_mpc.so ABI {lib.jsim_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

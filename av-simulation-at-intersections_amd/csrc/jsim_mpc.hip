@@ -22,6 +22,7 @@
 //   S5  outputs               predicted states of the linearised model, warm start, target_ind, active mask
 //                             reference: main/lib/mpc.py:200-205, 293-303
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -1266,6 +1267,7 @@ struct jsim_ctx {
     const int *cv_cut;      // caller-owned device array [B] or NULL
     size_t lds_bytes;
     const double *d_pe; // per-ego weights / limits (caller-owned device array) or NULL
+    void *comm;         // ncclComm_t of jsim_comm_init (RCCL), or NULL
     int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
     int dbg_max_gi;
     long long *dbg_clk; // diagnostic builds only
@@ -1370,6 +1372,7 @@ static void free_paths(jsim_ctx *c)
 extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->comm) (void)jsim_comm_destroy(ctx);
     DeviceGuard dev_guard(ctx->device);
     free_paths(ctx);
     if (ctx->d_pred_cc) (void)hipFree(ctx->d_pred_cc);
@@ -1620,6 +1623,95 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     launch_reg(c.T, B, s, P, K);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The job's one exchange: all-gather of the per-rank result blocks over RCCL (xGMI).  Egos are independent
+// (main/lib/mpc.py:141-211 couples nothing), so nothing is exchanged on the solve path; this is the final trajectory gather.
+// librccl is loaded on first use -- the library itself links only libamdhip64 and single-GPU users never touch RCCL.
+// ---------------------------------------------------------------------------------------------------
+struct JsimNcclId { char internal[128]; }; // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value like the original
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, JsimNcclId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+}
+static RcclApi g_rccl;
+
+static int rccl_load(jsim_ctx *ctx)
+{
+    if (g_rccl.h) return 0;
+    const char *names[] = {getenv("JSIM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if (n && n[0] && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(ctx, -2, "RCCL not found (librccl.so.1; set JSIM_RCCL_LIB): %s", dlerror());
+    RcclApi a;
+    a.h = h;
+    a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, JsimNcclId, int))dlsym(h, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString)
+        return fail(ctx, -2, "RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+    g_rccl = a;
+    return 0;
+}
+
+extern "C" int jsim_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(nullptr, -22, "jsim_comm_unique_id: null argument");
+    if (int rc = rccl_load(nullptr)) return rc;
+    const int r = g_rccl.GetUniqueId(id128);
+    if (r) return fail(nullptr, -5, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+    return 0;
+}
+
+extern "C" int jsim_comm_init(jsim_ctx *ctx, const void *id128, int32_t n_ranks, int32_t rank)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_comm_init: null ctx");
+    if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, -22, "jsim_comm_init: bad argument (rank %d of %d)", rank, n_ranks);
+    if (ctx->comm) return fail(ctx, -17, "jsim_comm_init: this context already has a communicator");
+    if (int rc = rccl_load(ctx)) return rc;
+    DeviceGuard dev_guard(ctx->device); // ncclCommInitRank binds the communicator to the current device
+    JsimNcclId id;
+    memcpy(&id, id128, sizeof(id));
+    void *comm = nullptr;
+    const int r = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
+    if (r) return fail(ctx, -5, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, g_rccl.GetErrorString(r));
+    ctx->comm = comm;
+    return 0;
+}
+
+extern "C" int jsim_mpc_gather(jsim_ctx *ctx, void *comm, const void *local, void *out, size_t bytes_per_rank, void *stream)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_gather: null ctx");
+    void *c = comm ? comm : ctx->comm;
+    if (!c) return fail(ctx, -22, "jsim_mpc_gather: no communicator (jsim_comm_init, or pass an ncclComm_t)");
+    if (bytes_per_rank == 0) return 0;
+    if (!local || !out) return fail(ctx, -22, "jsim_mpc_gather: null device pointer");
+    if (int rc = rccl_load(ctx)) return rc;
+    DeviceGuard dev_guard(ctx->device);
+    const int r = g_rccl.AllGather(local, out, bytes_per_rank, /* ncclChar */ 0, c, (hipStream_t)stream);
+    if (r) return fail(ctx, -5, "ncclAllGather: %s", g_rccl.GetErrorString(r));
+    return 0;
+}
+
+extern "C" int jsim_comm_destroy(jsim_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_comm_destroy: null ctx");
+    if (!ctx->comm) return 0;
+    DeviceGuard dev_guard(ctx->device);
+    const int r = g_rccl.h ? g_rccl.CommDestroy(ctx->comm) : 0;
+    ctx->comm = nullptr;
+    if (r) return fail(ctx, -5, "ncclCommDestroy: %s", g_rccl.GetErrorString(r));
     return 0;
 }
 

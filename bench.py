@@ -172,8 +172,12 @@ def main():
         for _ in range(W):          # warm-up (untimed)
             tick()
         torch.cuda.synchronize(device)
-        if world > 1:   # the job's one collective, run once untimed: communicator set-up and buffer registration are not the path
-            _ = pkg.sharding.gather_rows(loop.hist[:max(W, 1)].permute(1, 0, 2).contiguous(), B * world)
+        # the job's one exchange: torch.distributed's all_gather_into_tensor (default), or with JSIM_GATHER=cabi the C-ABI's own
+        # jsim_mpc_gather (ncclAllGather called by libjsim_mpc.so; needs one GPU per rank, so not in rehearsal mode)
+        cabi_gather = pkg.sharding.CabiGather(eng) if (world > 1 and os.environ.get("JSIM_GATHER") == "cabi" and not rehearsal) else None
+        gather = cabi_gather.gather_rows if cabi_gather else pkg.sharding.gather_rows
+        if world > 1:   # run once untimed: communicator set-up and buffer registration are not the path
+            _ = gather(loop.hist[:max(W, 1)].permute(1, 0, 2).contiguous(), B * world)
             torch.cuda.synchronize(device)
 
         chunk = next(c for c in (50, 25, 20, 10, 5, 4, 2, 1) if K % c == 0)
@@ -208,7 +212,7 @@ def main():
                 tick()
         if world > 1:   # the only exchange of the job: gather every rank's recorded controls (RCCL all-gather)
             hist_local = loop.hist[:K].permute(1, 0, 2).contiguous()          # [B, K, 2]
-            hist_all = pkg.sharding.gather_rows(hist_local, B * world)
+            hist_all = gather(hist_local, B * world)
             assert hist_all.shape[0] == B * world
         sync_all()
         t1 = time.perf_counter()
@@ -249,6 +253,8 @@ def main():
                    n_fail=int((eng.status != 0).sum().item()), respawns=int(loop.n_respawn.item()),
                    value=B * world * K / elapsed, routes=routes, batch=batch,
                    cut=(float(torch.stack(ncut[1:] + [(eng_cut_last)]).double().mean().item()) if cfg["scenario"] else None))
+        if cabi_gather:
+            cabi_gather.close()
         eng.close()
         return res
 

@@ -47,6 +47,7 @@
 #ifndef JSIM_MPC_H
 #define JSIM_MPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -204,6 +205,21 @@ int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, co
                        int32_t *status, int32_t *n_iter, double *di_ai, const double *x0_spawn,
                        const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist, int32_t *tick,
                        int32_t hist_cap, uint64_t *n_respawn, void *stream);
+
+/* ---- the job's one exchange: the final trajectory gather over RCCL / xGMI ----
+ * The reference has no multi-process code at all (its only multi-ego code is the serial Python loop of
+ * main/scenarios/interactive_mpc.py:119-172); egos are independent (main/lib/mpc.py:141-211), so ranks own contiguous shards
+ * of the ego batch and exchange nothing while solving.  These four calls are the gather of the per-rank result blocks:
+ *   jsim_comm_unique_id: fills a 128-byte ncclUniqueId (rank 0 calls it and hands the bytes to the other ranks by any means).
+ *   jsim_comm_init:      ncclCommInitRank on the context's device; the communicator then belongs to the context.
+ *   jsim_mpc_gather:     ncclAllGather of bytes_per_rank bytes from `local` into `out` [n_ranks * bytes_per_rank] (DEVICE pointers)
+ *                        on `stream`; comm == NULL uses the context's communicator, otherwise a caller-owned ncclComm_t.
+ *   jsim_comm_destroy:   ncclCommDestroy (also done by jsim_mpc_destroy).
+ * librccl is loaded on first use (dlopen; override with JSIM_RCCL_LIB): libjsim_mpc.so itself links only libamdhip64. */
+int jsim_comm_unique_id(void *id128);
+int jsim_comm_init(jsim_ctx *ctx, const void *id128, int32_t n_ranks, int32_t rank);
+int jsim_mpc_gather(jsim_ctx *ctx, void *comm, const void *local, void *out, size_t bytes_per_rank, void *stream);
+int jsim_comm_destroy(jsim_ctx *ctx);
 
 /* deviation [B] (needs ox[b][0], oy[b][0]) and is_goal [B] (int32 0/1); goal = last point of the FULL path. */
 int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id,

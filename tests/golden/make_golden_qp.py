@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""G3 fixtures: whole-step QP cases  inputs -> (status, target_ind, g, u*, multipliers, active set, iterations)
+for T in {13, 20, 30, 40}, >= 50 cases per horizon, written to tests/golden/qp_T<T>.npz.
+
+PARITY UNPINNED AGAINST ECOS.  The reference solves this QP with cvxpy -> ECOS (main/lib/mpc.py:196-199); neither is
+installed or pinned anywhere and the reference holds no fixtures for it, so these vectors are NOT reference outputs.  They
+are the CPU oracle's (oracle/mpc_oracle.c: exact Goldfarb-Idnani solve of the strictly convex condensed QP whose (H, g, G, h)
+equal an independent restatement of the reference's sparse cvxpy problem, tests/qp_sparse_numpy.py), and EVERY case is
+cross-checked at generation time, before it is written:
+  * scipy.optimize.minimize(method="trust-constr") on the same condensed QP agrees on u* (<= 1e-4 abs, north_star's bar;
+    that interior-point solver itself stops at ~1e-5 here: the differences are recorded in `du_scipy`) and does not find a
+    lower objective;
+  * the KKT residuals of (u*, lambda) are <= 1e-8 (scaled), multipliers >= 0, complementarity <= 1e-8;
+  * an equality-constrained re-solve on the reported active set reproduces u*.
+The QP is strictly convex (lambda_min(H) >= 2 min(R) = 0.02), so its optimum is unique: any exact solver must return these u*.
+
+Cases per horizon: 40 seeded random egos on the synthetic route table (truncated paths, 30 % near the path end) and 14
+crafted ones that put every constraint family into the active set -- steer-rate (D) and steer (S) rows, accel-upper (AU)
+and accel-lower (AL) rows, speed-upper (VU) and speed-lower (VL) rows -- plus the two infeasible starts (v0 > speed,
+v0 < MIN_SPEED: the reference's "Cannot solve mpc" path) and the coincident-rows start v0 = speed - MAX_ACCEL*dt, where
+`v1 <= speed` and `a0 <= MAX_ACCEL` are the same half-space and only the lowest row id may end up active.
+
+The GPU test tests/test_gpu_golden_qp.py compares the HIP path with these files WITHOUT loading the oracle.
+
+usage (from the repo root; trust-constr makes it slow: ~25 min on 8 cores):  python tests/golden/make_golden_qp.py
+"""
+import importlib
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+TS = (13, 20, 30, 40)
+N_RANDOM = 40
+N_H = 4          # cases per horizon whose full Hessian is stored (the others carry g only: H is (2T)^2 doubles)
+
+
+def fam(i, T):
+    return ("D" if i < 2 * T - 2 else "VU" if i < 3 * T - 1 else "VL" if i < 4 * T else
+            "AU" if i < 5 * T else "AL" if i < 6 * T else "S")
+
+
+def build_cases(pkg, routes, T):
+    """(x0 [x, y, v, yaw], path_id, path_len, target_ind, speed, oa, od, label) per case."""
+    S = pkg.synth
+    b = S.make_ego_batch(routes, N_RANDOM, T, seed=100 + T, truncate=True, near_end_frac=0.3)
+    cases = [(b.x0[i].copy(), int(b.path_id[i]), int(b.path_len[i]), int(b.target_ind[i]), float(b.speed[i]), b.oa[i].copy(),
+              b.od[i].copy(), "random") for i in range(N_RANDOM)]
+    z = np.zeros(T)
+    sp = 30 / 3.6
+
+    def add(rid, k, dx, dy, dyaw, v, target, label, path_len=None, speed=sp, oa=None, od=None):
+        r = routes[rid]
+        cases.append((np.array([r[k, 0] + dx, r[k, 1] + dy, v, r[k, 2] + dyaw]), rid, path_len or len(r), target, speed,
+                      z.copy() if oa is None else oa, z.copy() if od is None else od, label))
+
+    add(1, 0, 0, 0, 0, 0.0, 0, "standing start (AU)")
+    add(0, 330, 2.5, -2.5, -1.2, 6.0, 325, "offset + heading error inside the turn (D, S)")
+    add(0, 340, -1.5, 1.0, 0.9, 7.0, 336, "offset + heading error inside the turn, other side (D, S)")
+    add(0, 100, 0, 0, 0, 8.3, 95, "fast before a truncated path end (AL)", path_len=130)
+    add(3, 200, 0, 0, 0, 8.0, 196, "fast before a truncated path end, other route (AL)", path_len=225)
+    add(0, 50, 0, 0, 0, sp, 48, "at the speed cap, accelerating warm start (VU)", oa=np.full(T, 2.0))
+    add(5, 150, 0.2, 0.1, 0.05, sp - 0.05, 146, "just under the speed cap (VU)", oa=np.full(T, 1.0))
+    add(0, 300, 0, 0, np.pi, -4.9, 280, "reversing at the lower speed bound (VL)")
+    add(2, 400, 0, 0, np.pi, -4.95, 380, "reversing at the lower speed bound, other route (VL)")
+    add(1, 10, 0, 0, 0, 8.0, 5, "infeasible: v0 > speed", speed=5.0)
+    add(1, 10, 0, 0, 0, -5.5, 5, "infeasible: v0 < MIN_SPEED")
+    add(4, 60, 0, 0, 0, sp - 2.0 * 0.2, 57, "coincident rows: v0 = speed - MAX_ACCEL*dt", oa=np.full(T, 2.0))
+    add(7, 250, 0.4, -0.3, 0.3, 3.0, 246, "moderate offset at low speed (AU, S)")
+    add(9, 500, 0, 0, 0, 6.0, 497, "short remaining path (terminal cost on most steps)", path_len=520)
+    return cases
+
+
+def solve_case(args):
+    T, case = args
+    import oracle_py as O
+    import qp_sparse_numpy as QS
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+    pkg = importlib.import_module("av-simulation-at-intersections_amd")
+    routes = pkg.synth.make_route_table()
+    for r in routes:
+        pkg.synth.smooth_yaw_inplace(r[:, 2])
+    x0, rid, plen, tind, speed, oa, od, label = case
+    p = O.make_params(T=T)
+    r = routes[rid][:plen]
+    res = O.mpc_step(p, (x0[0], x0[1], x0[3], x0[2]), r[:, 0], r[:, 1], r[:, 2], tind, speed, oa=oa, od=od, want_qp=True)
+    out = {"status": res["status"], "target_ind": res["target_ind"], "n_iter": res["n_iter"], "label": label,
+           "oa": res["oa"], "od": res["od"], "lam": res["lam"], "mask": res["active_mask"], "active": res["active"],
+           "g": res.get("g", np.zeros(2 * T)), "H": res.get("H", np.zeros((2 * T, 2 * T))), "du_scipy": 0.0,
+           "ox": res["ox"], "oy": res["oy"], "ov": res["ov"], "oyaw": res["oyaw"]}
+    if res["status"] != 0:
+        return out
+    # ---- cross-checks on the condensed QP (staged oracle calls give G, h, skip)
+    st_, xref, idx, rend, t2 = O.calc_ref_trajectory(p, x0[0], x0[1], x0[2], r[:, 0], r[:, 1], r[:, 2], tind)
+    xbar = O.predict_motion(p, x0, oa, od)
+    st3, H, g, G, h, skip, fresp, Sens = O.build_qp(p, xref, xbar, x0, rend, speed)
+    assert st_ == 0 and st3 == 0 and np.array_equal(H, res["H"]) and np.array_equal(g, res["g"])
+    u = np.empty(2 * T); u[0::2] = res["oa"]; u[1::2] = res["od"]
+    lam = res["lam"]
+    stat, prim, dual, comp = QS.kkt_check(H, g, G, h, skip, u, lam)
+    sc = max(1.0, np.abs(g).max())
+    assert stat <= 1e-8 * sc and prim <= 1e-9 and dual == 0.0 and comp <= 1e-8 * sc, (label, stat, prim, dual, comp)
+    A = np.array(sorted(res["active"]), dtype=int)
+    K = np.block([[H, G[A].T], [G[A], np.zeros((len(A), len(A)))]])
+    sol = np.linalg.lstsq(K, np.concatenate([-g, h[A]]), rcond=None)[0]
+    assert np.abs(sol[:2 * T] - u).max() <= 2e-6, (label, np.abs(sol[:2 * T] - u).max())
+    keep = ~skip.astype(bool)
+    f = lambda x: 0.5 * x @ H @ x + g @ x
+    r2 = minimize(f, np.zeros(2 * T), jac=lambda x: H @ x + g, hess=lambda x: H, method="trust-constr",
+                  constraints=[LinearConstraint(G[keep], -np.inf, h[keep])],
+                  options={"gtol": 1e-9, "xtol": 1e-11, "barrier_tol": 1e-10, "maxiter": 2000})
+    du = float(np.abs(r2.x - u).max())
+    assert du <= 1e-4, (label, du, r2.status)   # the north_star tolerance on u*; trust-constr itself stops at ~1e-5 here
+    assert f(u) <= f(r2.x) + 1e-8 * max(1.0, abs(f(r2.x))), label
+    out["du_scipy"] = du
+    return out
+
+
+def main():
+    pkg = importlib.import_module("av-simulation-at-intersections_amd")
+    routes = pkg.synth.make_route_table()
+    for r in routes:
+        pkg.synth.smooth_yaw_inplace(r[:, 2])
+    for T in (tuple(int(a) for a in sys.argv[1:]) or TS):
+        cases = build_cases(pkg, routes, T)
+        with Pool(8) as pool:
+            outs = pool.map(solve_case, [(T, c) for c in cases], chunksize=1)
+        n = len(cases)
+        fams = set()
+        for o in outs:
+            fams |= {fam(i, T) for i in o["active"]}
+        assert {"D", "S", "AU", "AL", "VU", "VL"} <= fams, (T, fams)
+        assert sum(o["status"] == 1 for o in outs) >= 2 and n >= 50
+        ok = [i for i, o in enumerate(outs) if o["status"] == 0]
+        h_idx = np.array([ok[0], ok[len(ok) // 3], ok[2 * len(ok) // 3], N_RANDOM + 1], dtype=np.int64)[:N_H]
+        np.savez_compressed(
+            os.path.join(HERE, f"qp_T{T}.npz"),
+            x0=np.array([c[0] for c in cases]), path_id=np.array([c[1] for c in cases], dtype=np.int32),
+            path_len=np.array([c[2] for c in cases], dtype=np.int32), target_ind_in=np.array([c[3] for c in cases], dtype=np.int64),
+            speed=np.array([c[4] for c in cases]), oa_in=np.array([c[5] for c in cases]), od_in=np.array([c[6] for c in cases]),
+            status=np.array([o["status"] for o in outs], dtype=np.int32),
+            target_ind_out=np.array([o["target_ind"] for o in outs], dtype=np.int64),
+            n_iter=np.array([o["n_iter"] for o in outs], dtype=np.int32),
+            oa=np.array([o["oa"] for o in outs]), od=np.array([o["od"] for o in outs]), lam=np.array([o["lam"] for o in outs]),
+            active_mask=np.array([o["mask"] for o in outs], dtype=np.uint32), g=np.array([o["g"] for o in outs]),
+            ox=np.array([o["ox"] for o in outs]), oy=np.array([o["oy"] for o in outs]), ov=np.array([o["ov"] for o in outs]),
+            oyaw=np.array([o["oyaw"] for o in outs]),
+            H_idx=h_idx, H=np.array([outs[i]["H"] for i in h_idx]), du_scipy=np.array([o["du_scipy"] for o in outs]),
+            crafted_first=np.int64(N_RANDOM))
+        print(f"T={T}: {n} cases, {len(ok)} solved / {n - len(ok)} infeasible, families active {sorted(fams)}, "
+              f"max |u* - trust-constr| {max(o['du_scipy'] for o in outs):.2e}, mean n_iter {np.mean([outs[i]['n_iter'] for i in ok]):.1f}")
+
+
+if __name__ == "__main__":
+    main()

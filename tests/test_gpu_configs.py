@@ -231,3 +231,23 @@ def test_two_contexts_leave_the_callers_device_alone(pkg, routes):
     out = e1.read_back()
     assert np.array_equal(out["oa"], e1.oa.cpu().numpy()) and np.array_equal(out["status"], e1.status.cpu().numpy())
     assert np.array_equal(out["xref"], e1.xref.cpu().numpy()) and np.array_equal(out["target_ind"], e1.target_ind.cpu().numpy())
+
+
+def test_cabi_gather_single_rank(pkg, routes):
+    """jsim_comm_unique_id / jsim_comm_init / jsim_mpc_gather / jsim_comm_destroy (RCCL's ncclAllGather called by the library
+    itself) on the one GPU of the box: a communicator of one rank, the gather is then a device copy -- what can be checked
+    without a second GPU is that RCCL loads, the communicator comes up on the context's device and the bytes arrive.
+    (The N-rank form is the same call; bench.py takes it with JSIM_GATHER=cabi.)"""
+    batch = pkg.synth.make_ego_batch(routes, 32, 13, seed=3)
+    eng = engine(pkg, routes, batch, 13)
+    g = pkg.sharding.CabiGather(eng, rank=0, world=1)
+    local = torch.arange(32 * 6, dtype=torch.float64, device=eng.device).reshape(32, 3, 2)
+    out = g.gather_rows(local, 32)
+    torch.cuda.synchronize()
+    assert out.shape == (32, 3, 2) and torch.equal(out, local) and out.data_ptr() != local.data_ptr()
+    # a second init on the same context is refused, destroy is idempotent
+    buf = (__import__("ctypes").c_char * 128)()
+    assert eng.lib.jsim_comm_init(eng._ctx, buf, 1, 0) < 0
+    g.close(); g.close()
+    assert eng.lib.jsim_mpc_gather(eng._ctx, None, local.data_ptr(), out.data_ptr(), 8, None) < 0   # no communicator any more
+    assert b"no communicator" in eng.lib.jsim_last_error(eng._ctx)

@@ -254,3 +254,11 @@ def test_multi_lane_route_table_geometry(pkg):
                         end = {1: (-30.0, 3.0 + 4.0 * (gl - 1)), 2: (3.0 + 4.0 * (gl - 1), 30.0), 3: (30.0, -(3.0 + 4.0 * (gl - 1)))}[tn]
                         assert np.hypot(r[-1, 0] - end[0], r[-1, 1] - end[1]) < 0.1
     assert len(S.make_route_table()) == 12
+
+
+def test_gather_entry_points_argument_errors_without_gpu(pkg):
+    lib = pkg._cabi.load()
+    assert lib.jsim_mpc_gather(None, None, None, None, 8, None) < 0 and b"null ctx" in lib.jsim_last_error(None)
+    assert lib.jsim_comm_init(None, None, 1, 0) < 0
+    assert lib.jsim_comm_unique_id(None) < 0
+    assert lib.jsim_comm_destroy(None) < 0
