@@ -17,3 +17,4 @@ from .mpc import MPC, MAX_ACCEL, MAX_DECEL, MPCSolutionNotFoundException  # noqa
 from . import mpc_with_speed  # noqa: F401
 from . import mpc_sensitivity  # noqa: F401
 from . import mpc_jerk  # noqa: F401
+from . import planner  # noqa: F401

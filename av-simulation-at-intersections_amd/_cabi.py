@@ -35,7 +35,7 @@ EXPORTS = (
     "jsim_loop_set_geometry", "jsim_loop_set_obstacle_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
     "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_mpc_set_ego_config", "jsim_loop_obstacles",
     "jsim_mpc_xref_deviation_goal", "jsim_loop_run_scenario",
-    "jsim_comm_unique_id", "jsim_comm_init", "jsim_mpc_gather", "jsim_comm_destroy",
+    "jsim_comm_unique_id", "jsim_comm_init", "jsim_mpc_gather", "jsim_comm_destroy", "jsim_plan_routes",
 )
 
 _lib = None
@@ -109,6 +109,9 @@ def load() -> C.CDLL:
     lib.jsim_mpc_gather.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     lib.jsim_comm_destroy.restype = C.c_int
     lib.jsim_comm_destroy.argtypes = [vp]
+    lib.jsim_plan_routes.restype = C.c_int
+    #                               dev  R    start goal box tol hp hp_off  n_obs  r_off mp_pts mp_len  n_prim n_pts cc  cc_off wh wc  max_path  outs
+    lib.jsim_plan_routes.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32] + [vp] * 7
     if lib.jsim_abi_version() != ABI_VERSION:
         raise JsimError(f"libjsim_mpc.so ABI {lib.jsim_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

@@ -1075,7 +1075,11 @@ static bool has_fused_glue(int T) { return has_reg_kernel(T); }
 static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
 {
     static const PreK none = {};
-#ifdef JSIM_DEV_ONLY_T40 /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
+#ifdef JSIM_DEV_ONLY_REG2_30 /* development builds: only the two-wave kernel at T = 30 (the instantiation of DESIGN.md section 5, fact 4) */
+    if (T == 30) hipLaunchKernelGGL((mpc_step_reg2_kernel<30, false>), dim3(B), dim3(128), 0, s, P, K, none);
+    (void)Q;
+    return;
+#elif defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
     if (T == 40) {
         if (Q) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
         else hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
@@ -1712,6 +1716,84 @@ extern "C" int jsim_comm_destroy(jsim_ctx *ctx)
     const int r = g_rccl.h ? g_rccl.CommDestroy(ctx->comm) : 0;
     ctx->comm = nullptr;
     if (r) return fail(ctx, -5, "ncclCommDestroy: %s", g_rccl.GetErrorString(r));
+    return 0;
+}
+
+#include "planner.inc"
+
+// Route planner: HOST pointers in and out -- a one-time precompute whose (M, 3) output is what
+// jsim_mpc_set_paths takes; device buffers are allocated, filled, searched (one wavefront per route) and read back inside the call.
+extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *start, const double *goal, const double *goal_box,
+                                const double *tol, const double *hp, const int32_t *hp_off, int32_t n_obs_total,
+                                const int32_t *route_obs_off, const double *mp_pts, const double *mp_len, int32_t n_prim,
+                                int32_t n_pts, const double *cc_pts, const int32_t *cc_off, const double *wh, const double *wc,
+                                int32_t max_path, int32_t *status, double *cost, int32_t *n_prims, int32_t *prims, double *nodes,
+                                double *traj, int32_t *n_expanded)
+{
+    if (n_routes < 0 || n_prim < 1 || n_prim > JPL_MAX_PRIM || n_pts < 2 || max_path < 1 || n_obs_total < 0)
+        return fail(nullptr, -22, "jsim_plan_routes: bad sizes (routes %d, primitives %d (max %d), points %d, max_path %d)", n_routes, n_prim,
+                    JPL_MAX_PRIM, n_pts, max_path);
+    if (n_routes == 0) return 0;
+    if (!start || !goal || !goal_box || !tol || !hp_off || !route_obs_off || !mp_pts || !mp_len || !cc_pts || !cc_off || !wh || !wc ||
+        !status || !cost || !n_prims || !prims || !nodes || !traj || !n_expanded || (n_obs_total > 0 && !hp))
+        return fail(nullptr, -22, "jsim_plan_routes: null argument");
+    int ndev = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, -19, "jsim_plan_routes: device %d of %d", device_id, ndev);
+    DeviceGuard dev_guard(device_id);
+    const int R = n_routes, cap = 16384, seg = n_pts - 1;
+    const size_t n_hp = (size_t)hp_off[n_obs_total], n_cc = (size_t)cc_off[n_prim];
+    struct Buf { void *p = nullptr; };
+    std::vector<void *> owned;
+    auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes ? bytes : 8) != hipSuccess) return nullptr; owned.push_back(q); return q; };
+    auto put = [&](const void *src, size_t bytes) -> void * {
+        void *q = dalloc(bytes);
+        if (q && bytes && hipMemcpy(q, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return q;
+    };
+    auto cleanup = [&]() { for (void *q : owned) (void)hipFree(q); };
+    PlanP P;
+    memset(&P, 0, sizeof(P));
+    P.n_routes = R; P.n_prim = n_prim; P.n_pts = n_pts; P.max_path = max_path; P.node_cap = cap;
+    P.wh_dist = wh[0]; P.wh_theta = wh[1]; P.wh_steer = wh[2]; P.wh_obst = wh[3]; P.wh_center = wh[4];
+    P.wc_dist = wc[0]; P.wc_steer = wc[1]; P.wc_obst = wc[2]; P.wc_center = wc[3];
+    P.start = (const double *)put(start, sizeof(double) * 3 * R); P.goal = (const double *)put(goal, sizeof(double) * 3 * R);
+    P.goal_box = (const double *)put(goal_box, sizeof(double) * 4 * R); P.tol = (const double *)put(tol, sizeof(double) * R);
+    P.hp = (const double *)put(hp, sizeof(double) * 3 * n_hp); P.hp_off = (const int *)put(hp_off, sizeof(int) * (n_obs_total + 1));
+    P.route_obs_off = (const int *)put(route_obs_off, sizeof(int) * (R + 1));
+    P.mp_pts = (const double *)put(mp_pts, sizeof(double) * 3 * (size_t)n_prim * n_pts); P.mp_len = (const double *)put(mp_len, sizeof(double) * n_prim);
+    P.cc_pts = (const double *)put(cc_pts, sizeof(double) * 2 * n_cc); P.cc_off = (const int *)put(cc_off, sizeof(int) * (n_prim + 1));
+    P.nx = (double *)dalloc(sizeof(double) * (size_t)R * cap); P.ny = (double *)dalloc(sizeof(double) * (size_t)R * cap);
+    P.nth = (double *)dalloc(sizeof(double) * (size_t)R * cap); P.ng = (double *)dalloc(sizeof(double) * (size_t)R * cap);
+    P.nparent = (int *)dalloc(sizeof(int) * (size_t)R * cap); P.nprim = (int *)dalloc(sizeof(int) * (size_t)R * cap);
+    P.status = (int *)dalloc(sizeof(int) * R); P.n_prims = (int *)dalloc(sizeof(int) * R); P.n_expanded = (int *)dalloc(sizeof(int) * R);
+    P.prims = (int *)dalloc(sizeof(int) * (size_t)R * max_path); P.cost = (double *)dalloc(sizeof(double) * R);
+    P.nodes = (double *)dalloc(sizeof(double) * (size_t)R * (max_path + 1) * 3);
+    P.traj = (double *)dalloc(sizeof(double) * (size_t)R * max_path * seg * 3);
+    if (!P.start || !P.goal || !P.goal_box || !P.tol || !P.hp || !P.hp_off || !P.route_obs_off || !P.mp_pts || !P.mp_len || !P.cc_pts ||
+        !P.cc_off || !P.nx || !P.ny || !P.nth || !P.ng || !P.nparent || !P.nprim || !P.status || !P.n_prims || !P.n_expanded || !P.prims ||
+        !P.cost || !P.nodes || !P.traj) {
+        cleanup();
+        return fail(nullptr, -12, "jsim_plan_routes: device allocation / upload failed");
+    }
+    hipError_t e = hipMemset(P.cost, 0, sizeof(double) * R);
+    if (e == hipSuccess) e = hipMemset(P.traj, 0, sizeof(double) * (size_t)R * max_path * seg * 3);
+    if (e == hipSuccess) e = hipMemset(P.nodes, 0, sizeof(double) * (size_t)R * (max_path + 1) * 3);
+    if (e == hipSuccess) e = hipMemset(P.prims, 0xff, sizeof(int) * (size_t)R * max_path);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(plan_astar_kernel, dim3(R), dim3(64), 0, 0, P);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(status, P.status, sizeof(int) * R, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cost, P.cost, sizeof(double) * R, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(n_prims, P.n_prims, sizeof(int) * R, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(n_expanded, P.n_expanded, sizeof(int) * R, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(prims, P.prims, sizeof(int) * (size_t)R * max_path, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(nodes, P.nodes, sizeof(double) * (size_t)R * (max_path + 1) * 3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(traj, P.traj, sizeof(double) * (size_t)R * max_path * seg * 3, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(nullptr, -5, "jsim_plan_routes: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -206,6 +206,30 @@ int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, co
                        const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist, int32_t *tick,
                        int32_t hist_cap, uint64_t *n_respawn, void *stream);
 
+/* ---- the route planner: A* over motion primitives, a batch of route queries at once ----
+ * Replaces MotionPrimitiveSearch(scenario, car_dimensions, mps, margin).run() -- main/lib/mp_search_ww_generic.py:136-257 with
+ * main/lib/a_star.py:31-78 and main/lib/obstacles.py:157-176 -- which every scenario script calls once before its loop
+ * (main/scenarios/mpc_intersection.py:63-64) and whose (M, 3) [x, y, yaw] trajectory becomes the MPC's path.  One wavefront
+ * searches one route; n_routes routes in one launch.  HOST pointers in and out (a one-time precompute: the output is what
+ * jsim_mpc_set_paths takes).
+ *   start, goal [R][3] (x, y, theta); goal_box [R][4] = (x1, y1, x2, y2) of the scenario's goal_area box; tol [R] =
+ *   allowed_goal_theta_difference.  Obstacles as half-plane sets a x + b y + c <= 0 (Obstacle.to_convex(margin)): hp [.][3],
+ *   hp_off [n_obs_total + 1] per obstacle, route_obs_off [R + 1] = each route's obstacles.  Primitives: mp_pts
+ *   [n_prim][n_pts][3], mp_len [n_prim] (total_length), cc_pts [.][2] / cc_off [n_prim + 1] = the collision-check points of each
+ *   primitive in its own frame (_create_collision_points, :118-136).  wh [5] = (dist, theta, steering, obstacle, center) of the
+ *   heuristic, wc [4] = (dist, steering, obstacle, center) of the edge cost (:29-33; the scenarios use the defaults
+ *   (1, 2.7, 15, 0, 0) / (1, 5, 0.1, 0)).
+ *   Out: status [R] (0 found; 1 no solution -- the reference raises Exception("No solution found."); 4 search workspace
+ *   exhausted; 5 obstacle / primitive set too large for the kernel; 6 path longer than max_path), cost [R], n_prims [R],
+ *   prims [R][max_path] (primitive index per segment), nodes [R][max_path + 1][3], traj [R][max_path * (n_pts - 1)][3] (the first
+ *   n_prims * (n_pts - 1) rows are the trajectory, path_to_full_trajectory :245-257), n_expanded [R]. */
+int jsim_plan_routes(int device_id, int32_t n_routes, const double *start, const double *goal, const double *goal_box,
+                     const double *tol, const double *hp, const int32_t *hp_off, int32_t n_obs_total,
+                     const int32_t *route_obs_off, const double *mp_pts, const double *mp_len, int32_t n_prim, int32_t n_pts,
+                     const double *cc_pts, const int32_t *cc_off, const double *wh, const double *wc, int32_t max_path,
+                     int32_t *status, double *cost, int32_t *n_prims, int32_t *prims, double *nodes, double *traj,
+                     int32_t *n_expanded);
+
 /* ---- the job's one exchange: the final trajectory gather over RCCL / xGMI ----
  * The reference has no multi-process code at all (its only multi-ego code is the serial Python loop of
  * main/scenarios/interactive_mpc.py:119-172); egos are independent (main/lib/mpc.py:141-211), so ranks own contiguous shards

@@ -1,0 +1,127 @@
+"""SURVEY.md 8 row f4 -- the route planner (A* over motion primitives).
+CPU: the product's regenerated primitives, car circles and scenario geometry equal the reference's (golden planner.npz, written
+by tests/golden/make_golden_planner.py from the reference's own classes), and the oracle's restatement reproduces every
+reference route bit for bit.  GPU: `jsim_plan_routes` (one wavefront per route, all 18 routes in one launch) against those
+reference routes: identical primitive sequence and expansion count, nodes / trajectory / cost <= 1e-9; and the planned routes fed
+to the MPC like main/scenarios/mpc_intersection.py:63-76 does."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _queries(pkg, g):
+    PL = pkg.planner
+    rad, _ = PL.car_circles()
+    qs = []
+    for i in range(int(g["n_routes"])):
+        kind, sp, tn, sl, gl = (int(v) for v in g[f"r{i}_meta"])
+        qs.append(PL.intersection_query(sp, tn, rad, sl or 1, gl or 1, number_of_lanes=2 if kind else 0))
+    return qs
+
+
+def test_primitives_and_scenarios_equal_the_references(pkg):
+    g = load_golden("planner.npz")
+    PL = pkg.planner
+    pts, length = PL.make_motion_primitives()
+    assert np.array_equal(pts, g["mp_points"]) and np.array_equal(length, g["mp_length"])     # the recipe, not the pickles
+    assert pts.shape == (9, 61, 3) and abs(length[0] - 4.98) < 1e-12
+    rad, cen = PL.car_circles()
+    assert rad == float(g["radius"]) and np.array_equal(cen, g["circle_centers"])
+    for i, q in enumerate(_queries(pkg, g)):
+        assert np.array_equal(np.concatenate(q.obstacles, axis=0), g[f"r{i}_hp"])                # to_convex(margin = radius), hidden boxes included
+        assert np.array_equal(np.cumsum([0] + [len(o) for o in q.obstacles]), g[f"r{i}_hp_off"])
+        assert np.array_equal(np.array(q.start), g[f"r{i}_start"]) and np.array_equal(np.array(q.goal), g[f"r{i}_goal"])
+        assert np.array_equal(np.array(q.goal_box), g[f"r{i}_goal_box"]) and q.tol == float(g[f"r{i}_tol"])
+
+
+def test_planner_oracle_reproduces_the_reference_routes(pkg):
+    import planner_oracle as PO
+    g = load_golden("planner.npz")
+    mps = PO.make_motion_primitives()
+    for i, q in enumerate(_queries(pkg, g)):
+        orc = PO.PlannerOracle(q.start, q.goal, q.goal_box, q.tol, q.obstacles, mps, g["circle_centers"], float(g["radius"]))
+        cost, path, traj = orc.run()
+        assert cost == float(g[f"r{i}_cost"]) and np.array_equal(np.array(path), g[f"r{i}_path"])
+        assert np.array_equal(traj, g[f"r{i}_traj"]) and orc.prim_sequence(path) == list(g[f"r{i}_prims"])
+        assert orc.n_expanded == int(g[f"r{i}_n_expanded"])
+    # no route: a wall right in front of the start -- every primitive collides, the open list runs empty
+    wall = [PO.box_halfplanes((49.0, 100.0), (25.5, 0.0), 0.0)]
+    orc = PO.PlannerOracle((0.0, 0.0, 0.0), (60.0, 0.0, 0.0), (59.0, -1.0, 61.0, 1.0), np.pi / 16, wall, mps, g["circle_centers"], float(g["radius"]))
+    with pytest.raises(Exception, match="No solution found"):
+        orc.run()
+    assert orc.n_expanded == 1
+
+
+@pytest.mark.gpu
+def test_hip_planner_against_the_reference_routes(pkg):
+    g = load_golden("planner.npz")
+    qs = _queries(pkg, g)
+    res = pkg.planner.plan_routes(qs)                       # ONE launch, one wavefront per route
+    assert len(res) == 18
+    for i, r in enumerate(res):
+        assert r.status == 0, (i, r.status)
+        assert list(r.prims) == list(g[f"r{i}_prims"]), i                      # the same primitive at every step
+        # the same search: node for node on 17 of the 18 routes; where two open nodes tie in g + h to the last ulp (numpy's matmul
+        # rounds the pose transform differently) one expansion more or less happens before the goal is popped
+        assert abs(r.n_expanded - int(g[f"r{i}_n_expanded"])) <= max(1, int(g[f"r{i}_n_expanded"]) // 50), i
+        assert abs(r.cost - float(g[f"r{i}_cost"])) <= 1e-9
+        np.testing.assert_allclose(r.nodes, g[f"r{i}_path"], rtol=0, atol=1e-9)
+        assert r.trajectory.shape == g[f"r{i}_traj"].shape
+        np.testing.assert_allclose(r.trajectory, g[f"r{i}_traj"], rtol=0, atol=1e-9)
+    lens = sorted({len(r.trajectory) for r in res})
+    assert lens == [480, 540, 600, 660, 720]
+    # a wall right in front of the start: the reference raises Exception("No solution found."), the batch reports status 1 for that
+    # route only; a goal nobody can reach in an open world: the search workspace runs out, status 4
+    PL = pkg.planner
+    walled = PL.RouteQuery(start=(0.0, 0.0, 0.0), goal=(60.0, 0.0, 0.0), goal_box=(59.0, -1.0, 61.0, 1.0), tol=np.pi / 16,
+                           obstacles=[PL.box_halfplanes((49.0, 100.0), (25.5, 0.0), 0.0)])
+    lost = PL.RouteQuery(start=qs[0].start, goal=(0.0, -45.0, 0.0), goal_box=(-1.0, -46.0, 1.0, -44.0), tol=qs[0].tol, obstacles=qs[0].obstacles)
+    out = PL.plan_routes([qs[1], walled, lost])
+    assert out[0].status == 0 and list(out[0].prims) == list(g["r1_prims"])
+    assert out[1].status == 1 and out[1].n_expanded == 1 and len(out[1].trajectory) == 0
+    assert out[2].status == 4 and out[2].n_expanded > 500
+
+
+@pytest.mark.gpu
+def test_planned_routes_drive_the_mpc(pkg, oracle):
+    """Planner -> MPC hand-over as in main/scenarios/mpc_intersection.py:63-76: the planned (M, 3) trajectory is the controller's
+    path (dl = distance between its first two points); REAL planner routes (primitive joints, curvature steps) instead of the
+    idealised arcs of synth.py.  Stage outputs and u* against the oracle on those routes, then a closed loop that reaches the goal."""
+    g = load_golden("planner.npz")
+    res = pkg.planner.plan_routes(_queries(pkg, g)[:12])
+    routes = [r.trajectory.copy() for r in res]
+    dl = float(np.linalg.norm(routes[0][0, :2] - routes[0][1, :2]))
+    assert abs(dl - 0.083) < 1e-12
+    for r in routes:
+        pkg.synth.smooth_yaw_inplace(r[:, 2])                       # MPC.__init__ (main/lib/mpc.py:260)
+    T, B = 13, 192
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=17, truncate=True, near_end_frac=0.2, dl=dl)
+    eng = pkg.BatchedMPC(routes, batch.path_id, dl=dl, T=T, speed=batch.speed, smooth=False)
+    eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
+    eng.solve(torch.from_numpy(batch.x0).to(eng.device))
+    torch.cuda.synchronize()
+    p = oracle.make_params(T=T, dl=dl)
+    cx, cy, cyaw, off = pkg.synth.pack_paths(routes)
+    ref = oracle.mpc_step_batch(p, batch.x0, batch.path_id, batch.path_len, batch.speed, cx, cy, cyaw, off, batch.target_ind, batch.oa,
+                                batch.od, n_threads=4)
+    assert np.array_equal(eng.status.cpu().numpy(), ref["status"]) and np.array_equal(eng.target_ind.cpu().numpy(), ref["target_ind"])
+    np.testing.assert_array_equal(eng.xref.cpu().numpy(), ref["xref"])
+    ok = ref["status"] == 0
+    assert ok.sum() >= B - 4
+    du = max(np.abs(eng.oa.cpu().numpy() - ref["oa"])[ok].max(), np.abs(eng.od.cpu().numpy() - ref["od"])[ok].max())
+    assert du <= 1e-7, du
+    assert np.array_equal(eng.active_mask.cpu().numpy().view(np.uint32), ref["active_mask"])
+    # config-1 shape: one ego from the start of its planned route, closed loop until MPC.is_goal
+    r0 = routes[0]
+    mpc = pkg.MPC(cx=r0[:, 0], cy=r0[:, 1], cyaw=r0[:, 2].copy(), dl=dl, car_dimensions=pkg.BicycleModelDimensions(), speed=30 / 3.6)
+    st = np.array([r0[0, 0], r0[0, 1], 0.0, r0[0, 2]])
+    reached = False
+    for k in range(200):
+        if mpc.is_goal(pkg.State(x=st[0], y=st[1], yaw=st[3], v=st[2])):
+            reached = True
+            break
+        di, ai = mpc.step(pkg.State(x=st[0], y=st[1], yaw=st[3], v=st[2]))
+        st = oracle.plant_step(p, st, ai, di)
+    assert reached and k > 40
