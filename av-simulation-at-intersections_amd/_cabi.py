@@ -111,7 +111,7 @@ def load() -> C.CDLL:
     lib.jsim_comm_destroy.argtypes = [vp]
     lib.jsim_plan_routes.restype = C.c_int
     #                               dev  R    start goal box tol hp hp_off  n_obs  r_off mp_pts mp_len  n_prim n_pts cc  cc_off wh wc  max_path  outs
-    lib.jsim_plan_routes.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32] + [vp] * 7
+    lib.jsim_plan_routes.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32] + [vp] * 7
     if lib.jsim_abi_version() != ABI_VERSION:
         raise JsimError(f"libjsim_mpc.so ABI {lib.jsim_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

@@ -1727,10 +1727,10 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
                                 const double *tol, const double *hp, const int32_t *hp_off, int32_t n_obs_total,
                                 const int32_t *route_obs_off, const double *mp_pts, const double *mp_len, int32_t n_prim,
                                 int32_t n_pts, const double *cc_pts, const int32_t *cc_off, const double *wh, const double *wc,
-                                int32_t max_path, int32_t *status, double *cost, int32_t *n_prims, int32_t *prims, double *nodes,
-                                double *traj, int32_t *n_expanded)
+                                int32_t max_path, int32_t node_cap, int32_t *status, double *cost, int32_t *n_prims, int32_t *prims,
+                                double *nodes, double *traj, int32_t *n_expanded)
 {
-    if (n_routes < 0 || n_prim < 1 || n_prim > JPL_MAX_PRIM || n_pts < 2 || max_path < 1 || n_obs_total < 0)
+    if (n_routes < 0 || n_prim < 1 || n_prim > JPL_MAX_PRIM || n_pts < 2 || max_path < 1 || n_obs_total < 0 || node_cap < 64 || node_cap > (1 << 24))
         return fail(nullptr, -22, "jsim_plan_routes: bad sizes (routes %d, primitives %d (max %d), points %d, max_path %d)", n_routes, n_prim,
                     JPL_MAX_PRIM, n_pts, max_path);
     if (n_routes == 0) return 0;
@@ -1741,7 +1741,9 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -19, "jsim_plan_routes: device %d of %d", device_id, ndev);
     DeviceGuard dev_guard(device_id);
-    const int R = n_routes, cap = 16384, seg = n_pts - 1;
+    const int R = n_routes, cap = node_cap, seg = n_pts - 1;
+    int hash_cap = 128;
+    while (hash_cap < 2 * cap) hash_cap <<= 1;
     const size_t n_hp = (size_t)hp_off[n_obs_total], n_cc = (size_t)cc_off[n_prim];
     struct Buf { void *p = nullptr; };
     std::vector<void *> owned;
@@ -1766,17 +1768,21 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     P.nx = (double *)dalloc(sizeof(double) * (size_t)R * cap); P.ny = (double *)dalloc(sizeof(double) * (size_t)R * cap);
     P.nth = (double *)dalloc(sizeof(double) * (size_t)R * cap); P.ng = (double *)dalloc(sizeof(double) * (size_t)R * cap);
     P.nparent = (int *)dalloc(sizeof(int) * (size_t)R * cap); P.nprim = (int *)dalloc(sizeof(int) * (size_t)R * cap);
+    P.htab = (int *)dalloc(sizeof(int) * (size_t)R * hash_cap); P.hash_cap = hash_cap;
+    P.ov_gh = (double *)dalloc(sizeof(double) * (size_t)R * cap); P.ov_g = (double *)dalloc(sizeof(double) * (size_t)R * cap);
+    P.ov_id = (int *)dalloc(sizeof(int) * (size_t)R * cap);
     P.status = (int *)dalloc(sizeof(int) * R); P.n_prims = (int *)dalloc(sizeof(int) * R); P.n_expanded = (int *)dalloc(sizeof(int) * R);
     P.prims = (int *)dalloc(sizeof(int) * (size_t)R * max_path); P.cost = (double *)dalloc(sizeof(double) * R);
     P.nodes = (double *)dalloc(sizeof(double) * (size_t)R * (max_path + 1) * 3);
     P.traj = (double *)dalloc(sizeof(double) * (size_t)R * max_path * seg * 3);
     if (!P.start || !P.goal || !P.goal_box || !P.tol || !P.hp || !P.hp_off || !P.route_obs_off || !P.mp_pts || !P.mp_len || !P.cc_pts ||
-        !P.cc_off || !P.nx || !P.ny || !P.nth || !P.ng || !P.nparent || !P.nprim || !P.status || !P.n_prims || !P.n_expanded || !P.prims ||
+        !P.cc_off || !P.nx || !P.ny || !P.nth || !P.ng || !P.nparent || !P.nprim || !P.htab || !P.ov_gh || !P.ov_g || !P.ov_id || !P.status || !P.n_prims || !P.n_expanded || !P.prims ||
         !P.cost || !P.nodes || !P.traj) {
         cleanup();
         return fail(nullptr, -12, "jsim_plan_routes: device allocation / upload failed");
     }
     hipError_t e = hipMemset(P.cost, 0, sizeof(double) * R);
+    if (e == hipSuccess) e = hipMemset(P.htab, 0xff, sizeof(int) * (size_t)R * hash_cap);
     if (e == hipSuccess) e = hipMemset(P.traj, 0, sizeof(double) * (size_t)R * max_path * seg * 3);
     if (e == hipSuccess) e = hipMemset(P.nodes, 0, sizeof(double) * (size_t)R * (max_path + 1) * 3);
     if (e == hipSuccess) e = hipMemset(P.prims, 0xff, sizeof(int) * (size_t)R * max_path);

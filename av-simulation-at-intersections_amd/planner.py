@@ -158,8 +158,18 @@ class PlannedRoute:
 
 
 def plan_routes(queries: Sequence[RouteQuery], L: float = 2.86, wh=WH_DEFAULT, wc=WC_DEFAULT, max_path: int = 32,
-                device: int = 0, primitives=None) -> List[PlannedRoute]:
-    """All queries in ONE launch (one wavefront per route)."""
+                device: int = 0, primitives=None, node_cap: int = 16384, retry_node_cap: int = 1 << 19) -> List[PlannedRoute]:
+    """All queries in ONE launch (one wavefront per route).  Routes whose search outgrows `node_cap` nodes (status 4) are planned
+    again, together, with `retry_node_cap` (0: no second attempt)."""
+    out = _plan(queries, L, wh, wc, max_path, device, primitives, node_cap)
+    again = [i for i, r in enumerate(out) if r.status == 4]
+    if again and retry_node_cap > node_cap:
+        for i, r in zip(again, _plan([queries[i] for i in again], L, wh, wc, max_path, device, primitives, retry_node_cap)):
+            out[i] = r
+    return out
+
+
+def _plan(queries, L, wh, wc, max_path, device, primitives, node_cap) -> List[PlannedRoute]:
     lib = _cabi.load()
     pts, length = primitives if primitives is not None else make_motion_primitives(L=L)
     radius, centres = car_circles(L=L)
@@ -189,7 +199,7 @@ def plan_routes(queries: Sequence[RouteQuery], L: float = 2.86, wh=WH_DEFAULT, w
     n_exp = np.zeros(R, dtype=np.int32)
     p = lambda a: C.c_void_p(a.ctypes.data)
     _cabi.check(lib.jsim_plan_routes(int(device), R, p(start), p(goal), p(box), p(tol), p(hp), p(hp_off), len(hp_off) - 1, p(r_off), p(mp),
-                                     p(ml), n_prim, n_pts, p(cc_flat), p(cc_off), p(whv), p(wcv), int(max_path), p(status), p(cost),
+                                     p(ml), n_prim, n_pts, p(cc_flat), p(cc_off), p(whv), p(wcv), int(max_path), int(node_cap), p(status), p(cost),
                                      p(n_prims), p(prims), p(nodes), p(traj), p(n_exp)), None, "jsim_plan_routes")
     out = []
     for i in range(R):

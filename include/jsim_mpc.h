@@ -219,6 +219,8 @@ int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, co
  *   primitive in its own frame (_create_collision_points, :118-136).  wh [5] = (dist, theta, steering, obstacle, center) of the
  *   heuristic, wc [4] = (dist, steering, obstacle, center) of the edge cost (:29-33; the scenarios use the defaults
  *   (1, 2.7, 15, 0, 0) / (1, 5, 0.1, 0)).
+ *   node_cap: search workspace per route in nodes (16384 covers the reference's 18 standard routes a hundred times over; a
+ *   route that reports status 4 wants more -- the two-lane scenario's lane changes need up to ~250k).
  *   Out: status [R] (0 found; 1 no solution -- the reference raises Exception("No solution found."); 4 search workspace
  *   exhausted; 5 obstacle / primitive set too large for the kernel; 6 path longer than max_path), cost [R], n_prims [R],
  *   prims [R][max_path] (primitive index per segment), nodes [R][max_path + 1][3], traj [R][max_path * (n_pts - 1)][3] (the first
@@ -227,7 +229,7 @@ int jsim_plan_routes(int device_id, int32_t n_routes, const double *start, const
                      const double *tol, const double *hp, const int32_t *hp_off, int32_t n_obs_total,
                      const int32_t *route_obs_off, const double *mp_pts, const double *mp_len, int32_t n_prim, int32_t n_pts,
                      const double *cc_pts, const int32_t *cc_off, const double *wh, const double *wc, int32_t max_path,
-                     int32_t *status, double *cost, int32_t *n_prims, int32_t *prims, double *nodes, double *traj,
+                     int32_t node_cap, int32_t *status, double *cost, int32_t *n_prims, int32_t *prims, double *nodes, double *traj,
                      int32_t *n_expanded);
 
 /* ---- the job's one exchange: the final trajectory gather over RCCL / xGMI ----

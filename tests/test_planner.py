@@ -78,10 +78,21 @@ def test_hip_planner_against_the_reference_routes(pkg):
     walled = PL.RouteQuery(start=(0.0, 0.0, 0.0), goal=(60.0, 0.0, 0.0), goal_box=(59.0, -1.0, 61.0, 1.0), tol=np.pi / 16,
                            obstacles=[PL.box_halfplanes((49.0, 100.0), (25.5, 0.0), 0.0)])
     lost = PL.RouteQuery(start=qs[0].start, goal=(0.0, -45.0, 0.0), goal_box=(-1.0, -46.0, 1.0, -44.0), tol=qs[0].tol, obstacles=qs[0].obstacles)
-    out = PL.plan_routes([qs[1], walled, lost])
+    out = PL.plan_routes([qs[1], walled, lost], node_cap=8192, retry_node_cap=0)
     assert out[0].status == 0 and list(out[0].prims) == list(g["r1_prims"])
     assert out[1].status == 1 and out[1].n_expanded == 1 and len(out[1].trajectory) == 0
     assert out[2].status == 4 and out[2].n_expanded > 500
+    # a lane change of the two-lane scenario whose search is two orders of magnitude larger (the reference's Python: ~4.5 s, 2741
+    # expansions, 8380 open nodes): first attempt runs out of workspace, the automatic second one finds the reference's route
+    import planner_oracle as PO
+    hard = PL.intersection_query(3, 3, PL.car_circles()[0], 1, 2, number_of_lanes=2)
+    r = PL.plan_routes([hard], node_cap=4096)[0]
+    orc = PO.PlannerOracle(hard.start, hard.goal, hard.goal_box, hard.tol, hard.obstacles, PO.make_motion_primitives(), g["circle_centers"],
+                           float(g["radius"]))
+    c2, p2, t2 = orc.run()
+    assert r.status == 0 and list(r.prims) == orc.prim_sequence(p2) and abs(r.cost - c2) <= 1e-9
+    np.testing.assert_allclose(r.trajectory, t2, rtol=0, atol=1e-9)
+    assert abs(r.n_expanded - orc.n_expanded) <= orc.n_expanded // 50
 
 
 @pytest.mark.gpu
