@@ -89,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--ticks-per-launch", type=int, default=0,
                     help="fused mode: closed-loop ticks per kernel launch (0 = all K ticks of the timed region in one launch; "
                          "egos only wait for each other at launch boundaries)")
+    ap.add_argument("--routes", choices=("planner", "synthetic"), default="planner",
+                    help="planner (default): the route table is planned on the GPU (jsim_plan_routes: A* over motion primitives on the "
+                         "reference's intersection geometry, 12 routes / 48 two-lane routes, untimed set-up); synthetic: idealised arcs")
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the config 4 / config 5 per-rank shares")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
@@ -150,13 +153,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    _route_cache = {}
+
+    def route_table(multi_lane):
+        """the 12 routes of the reference's intersection() (configs 2-4) or of its two-lane scenario (config 5:
+        4 arms x 3 turns x 2 start lanes x 2 goal lanes = 48), planned here by the GPU planner (row f4); yaw unwrapped like MPC.__init__."""
+        if multi_lane not in _route_cache:
+            if args.routes == "synthetic":
+                rs = S.make_route_table(multi_lane=multi_lane)
+            else:
+                PL = pkg.planner
+                rad, _ = PL.car_circles()
+                if multi_lane:
+                    qs = [PL.intersection_query(sp, tn, rad, sl, gl, number_of_lanes=2) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)
+                          for sl in (1, 2) for gl in (1, 2)]
+                else:
+                    qs = [PL.intersection_query(sp, tn, rad) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)]
+                res = PL.plan_routes(qs, device=dev_index)
+                if any(r.status != 0 for r in res):
+                    raise SystemExit(f"route planner: status {[r.status for r in res]}")
+                rs = [r.trajectory for r in res]
+            for r in rs:
+                S.smooth_yaw_inplace(r[:, 2])
+            _route_cache[multi_lane] = rs
+        return _route_cache[multi_lane]
+
     def run_workload(cfg_id, B, T, K, W, mode, tpl):
         """W untimed ticks, then EXACTLY K timed ticks bracketed by barrier + synchronize; returns the figures of this rank
         (elapsed = max over ranks)."""
         cfg = CONFIGS[cfg_id]
-        routes = S.make_route_table(multi_lane=cfg["multi_lane"])
-        for r in routes:
-            S.smooth_yaw_inplace(r[:, 2])
+        routes = route_table(cfg["multi_lane"])
         batch = S.make_ego_batch(routes, B, T, seed=1 + rank, truncate=False)
         eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device=device, smooth=False)
         eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
@@ -299,7 +325,9 @@ def main():
             "config": {"workload": f"{B} egos per GPU, horizon N={T}, nu=2, fp64, closed loop -- "
                                    + (cfg["name"] if (B, T) == (cfg["batch"], cfg["horizon"]) else "not a named configuration"),
                        "baseline_config": args.config, "egos_per_gpu": B, "egos_total": B * world, "horizon": T,
-                       "routes": "multi-lane synthetic" if cfg["multi_lane"] else "synthetic 4-arm intersection, 12 routes",
+                       "routes": (("48 two-lane routes" if cfg["multi_lane"] else "12 intersection routes") +
+                                  (" planned on the GPU (A* over motion primitives, the reference's scenario geometry)" if args.routes == "planner"
+                                   else ", synthetic arcs")),
                        "launch": {"fused": f"fused closed loop, {r['chunk']} ticks per launch", "graph": "hipGraph",
                                   "eager": "eager"}[r["mode"]], "parallelism": f"ego-shard x{world}",
                        "mean_active_set_iters": round(r["mean_iter"], 2), "failed_egos_last_tick": r["n_fail"],
