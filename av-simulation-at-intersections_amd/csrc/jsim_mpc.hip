@@ -1272,6 +1272,10 @@ struct jsim_ctx {
     size_t lds_bytes;
     const double *d_pe; // per-ego weights / limits (caller-owned device array) or NULL
     void *comm;         // ncclComm_t of jsim_comm_init (RCCL), or NULL
+    int *d_order;       // launch order of the fused closed-loop launches (prepare_launch_order) ..
+    unsigned *d_work;   // .. and the per-ego iteration count of the previous launch it is derived from
+    int order_cap;
+    int order_mode;     // 0: from the environment (default on), 1: on, -1: off (jsim_mpc_set_launch_order)
     int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
     int dbg_max_gi;
     long long *dbg_clk; // diagnostic builds only
@@ -1384,6 +1388,8 @@ extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
     if (ctx->d_pred_all) (void)hipFree(ctx->d_pred_all);
     if (ctx->d_bc_all) (void)hipFree(ctx->d_bc_all);
     if (ctx->d_pred_bc) (void)hipFree(ctx->d_pred_bc);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     delete ctx;
 }
 
@@ -1451,6 +1457,73 @@ static void fill_kp(const jsim_ctx *ctx, int32_t B, KP &P)
     P.vmax_plant = c.max_speed; P.vmin = c.min_speed; P.vref_min = c.min_ref_speed;
     P.pxy = ctx->d_pxy; P.pyaw = ctx->d_pyaw; P.poff = ctx->d_poff;
     P.pcv = ctx->d_pcv; P.cv_cut = ctx->cv_cut; P.pe = ctx->d_pe;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Launch order of the fused closed-loop launches.  A launch ends when its slowest ego does, and with more egos than
+// the chip holds at once (1024 one-wave egos at T = 13 / 20 / 30, 512 four-wave egos at T = 40) the workgroups of the
+// second round start when a slot frees up: an ego far from its path -- four to five times the mean number of active-set
+// iterations per tick, tick after tick -- that starts late ends the launch late.  Workgroups are dispatched in blockIdx
+// order, so workgroup b is given ego order[b], the egos ranked by the iterations they needed in the PREVIOUS launch, most
+// first (longest-processing-time-first list scheduling).  Egos are independent: the order changes when an ego is solved,
+// never what is computed for it.  JSIM_LAUNCH_ORDER=0 in the environment keeps the identity order (A/B runs).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void launch_order_kernel(const unsigned *work, int B, int *order)
+{
+    __shared__ unsigned tile[1024];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned wi = i < B ? work[i] : 0u;
+    int rank = 0; // egos ahead of ego i: more work, or the same work and a lower index (a permutation whatever the values)
+    for (int base = 0; base < B; base += 1024) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = base + j < B ? work[base + j] : 0u;
+        __syncthreads();
+        const int n = B - base < 1024 ? B - base : 1024;
+        for (int j = 0; j < n; ++j) {
+            const unsigned wj = tile[j];
+            rank += (wj > wi || (wj == wi && base + j < i)) ? 1 : 0;
+        }
+    }
+    if (i < B) order[rank] = i;
+}
+
+static int prepare_launch_order(jsim_ctx *ctx, int B, hipStream_t s, TickP &K)
+{
+    static const int enabled = [] { const char *e = getenv("JSIM_LAUNCH_ORDER"); return !(e && e[0] == '0'); }();
+    K.order = nullptr; K.work = nullptr;
+    const bool on = ctx->order_mode ? ctx->order_mode > 0 : (bool)enabled;
+    if (!on || B < 512 || B > 65536) return 0; // fewer egos than slots: all start at once; beyond: O(B^2) ranking not worth it
+    if (ctx->order_cap < B) {
+        if (ctx->d_order) (void)hipFree(ctx->d_order);
+        if (ctx->d_work) (void)hipFree(ctx->d_work);
+        ctx->d_order = nullptr; ctx->d_work = nullptr; ctx->order_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_order, sizeof(int) * (size_t)B));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_work, sizeof(unsigned) * (size_t)B));
+        ctx->order_cap = B;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned) * (size_t)B, s));
+    }
+    hipLaunchKernelGGL(launch_order_kernel, dim3((B + 255) / 256), dim3(256), 0, s, ctx->d_work, B, ctx->d_order);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned) * (size_t)B, s));
+    K.order = ctx->d_order; K.work = ctx->d_work;
+    return 0;
+}
+
+extern "C" int jsim_mpc_set_launch_order(jsim_ctx *ctx, int32_t enabled)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_launch_order: null ctx");
+    ctx->order_mode = enabled ? 1 : -1;
+    return 0;
+}
+
+extern "C" int jsim_mpc_get_launch_order(jsim_ctx *ctx, int32_t B, int32_t *order, uint32_t *work)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_get_launch_order: null ctx");
+    DeviceGuard dev_guard(ctx->device);
+    if (B <= 0 || B > ctx->order_cap) return fail(ctx, -22, "jsim_mpc_get_launch_order: B=%d, but the last ordered launch had %d egos", B, ctx->order_cap);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (order) HIP_TRY(ctx, hipMemcpy(order, ctx->d_order, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    if (work) HIP_TRY(ctx, hipMemcpy(work, ctx->d_work, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t *path_id, const int32_t *path_len,
@@ -1624,6 +1697,7 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     K.max_decel = c.max_decel; K.goal_dis = c.goal_dis; K.stop_speed = c.stop_speed;
     K.x0w = x0; K.di_ai = di_ai; K.x0_spawn = x0_spawn; K.target_spawn = (const long long *)target_spawn; K.age = age;
     K.hist = hist; K.tick = tick; K.n_respawn = (unsigned long long *)n_respawn;
+    if (int rc_ = prepare_launch_order(ctx, B, s, K)) return rc_;
     launch_reg(c.T, B, s, P, K);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());
@@ -2048,6 +2122,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     Q.pred_cc_all = ctx->d_pred_all; Q.pred_bc_all = ctx->d_bc_all; Q.traj_idx = (long long *)traj_idx; Q.prev_len = prev_path_len; Q.path_len_out = path_len;
     Q.col_flag = col_flag; Q.pre_status = pre_status;
     Q.speed_cutoff = speed_cutoff ? 1 : 0; Q.cut_io = glue_out;
+    if (int rc_ = prepare_launch_order(ctx, B, s, K)) return rc_;
     launch_reg(c.T, B, s, P, K, &Q);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());

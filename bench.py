@@ -188,7 +188,7 @@ def main():
         eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
         x0 = torch.from_numpy(batch.x0).to(device)
         if cfg["scenario"]:
-            sc = pkg.ScenarioLoop(eng, x0, OBSTACLE_SPECS, hist_cap=K + W + 8, max_age=400)
+            sc = pkg.ScenarioLoop(eng, x0, OBSTACLE_SPECS, hist_cap=K + W + 64, max_age=400)
             loop, tick, run = sc.loop, sc.tick, sc.run
             mode = "fused" if mode == "graph" else mode
         else:
@@ -213,7 +213,9 @@ def main():
             chunk = tpl if tpl > 0 else (chunk if cfg["scenario"] else K)
             if K % chunk:
                 raise SystemExit(f"--ticks-per-launch {chunk} must divide --steps {K}")
-            run(1)                  # untimed: first use of the entry point
+            # untimed: first use of the entry point (the scenario entry sizes its per-launch obstacle buffers on first use, so
+            # it is given a launch of the timed size)
+            run(chunk if cfg["scenario"] else 1)
         elif mode == "graph":
             loop.capture(chunk)     # (capture runs one extra untimed tick)
 
@@ -316,7 +318,7 @@ def main():
                 traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (tpl / float(pmc.get("ticks_per_launch", 100)))
                 traffic_source = (f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc passes of this command "
                                   f"({pmc.get('ticks_per_launch', 100)} ticks per launch), scaled to {tpl} ticks; stale if the kernel changed since")
-        waves = 2 if T == 40 else 1
+        waves = 4 if T == 40 else 1
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",
             "value": r["value"], "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,

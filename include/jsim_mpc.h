@@ -206,6 +206,16 @@ int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, co
                        const int64_t *target_spawn, int32_t *age, int32_t max_age, double *hist, int32_t *tick,
                        int32_t hist_cap, uint64_t *n_respawn, void *stream);
 
+/* Launch order of the fused closed-loop launches (jsim_mpc_run_ticks, jsim_loop_run_scenario).  No reference counterpart:
+ * the reference runs one vehicle per process (main/scenarios/mpc_intersection.py:99); this is scheduling of the batch only.
+ * With 512 <= B <= 65536 workgroup b of a launch is given the ego that ranked b-th by the active-set iterations it needed in
+ * the previous launch of this context (most first), so that the egos far from their paths do not start last; results are
+ * those of the identity order bit for bit.  On by default (JSIM_LAUNCH_ORDER=0 in the environment turns it off);
+ * jsim_mpc_set_launch_order overrides the environment for one context.  jsim_mpc_get_launch_order copies the order used by
+ * the last launch and the iteration counts that launch recorded to HOST arrays [B] (either may be NULL); it synchronises. */
+int jsim_mpc_set_launch_order(jsim_ctx *ctx, int32_t enabled);
+int jsim_mpc_get_launch_order(jsim_ctx *ctx, int32_t B, int32_t *order, uint32_t *work);
+
 /* ---- the route planner: A* over motion primitives, a batch of route queries at once ----
  * Replaces MotionPrimitiveSearch(scenario, car_dimensions, mps, margin).run() -- main/lib/mp_search_ww_generic.py:136-257 with
  * main/lib/a_star.py:31-78 and main/lib/obstacles.py:157-176 -- which every scenario script calls once before its loop

@@ -251,3 +251,52 @@ def test_cabi_gather_single_rank(pkg, routes):
     g.close(); g.close()
     assert eng.lib.jsim_mpc_gather(eng._ctx, None, local.data_ptr(), out.data_ptr(), 8, None) < 0   # no communicator any more
     assert b"no communicator" in eng.lib.jsim_last_error(eng._ctx)
+
+
+@pytest.mark.parametrize("T,scenario", ((13, False), (20, True), (40, False)))
+def test_launch_order_changes_when_not_what(pkg, routes, T, scenario):
+    """jsim_mpc_set_launch_order: with B >= 512 the fused launches hand workgroup b the ego that ranked b-th by the
+    iterations of the previous launch.  (1) the history, final state and per-ego outputs are those of the identity order bit
+    for bit (three launches, plain loop and scenario loop with its in-kernel glue); (2) the order used by launch k+1 is
+    the stable descending sort of the iteration counts launch k recorded."""
+    import ctypes as C
+    B, K = 640, 4
+    batch = pkg.synth.make_ego_batch(routes, B, T, seed=23, near_end_frac=0.2)
+    specs = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None), dict(direction=-1, turning=True, speed=20 / 3.6, offset=1.0)]
+
+    def make(enabled):
+        eng = engine(pkg, routes, batch, T)
+        pkg._cabi.check(eng.lib.jsim_mpc_set_launch_order(eng._ctx, 1 if enabled else 0), eng._ctx)
+        x0 = torch.from_numpy(batch.x0).to(eng.device)
+        if scenario:
+            sc = pkg.ScenarioLoop(eng, x0, specs, hist_cap=3 * K, max_age=400)
+            return eng, sc.loop, sc.run
+        loop = pkg.ClosedLoop(eng, x0, hist_cap=3 * K, max_age=400)
+        return eng, loop, loop.run
+
+    def order_and_work(eng):
+        o = np.zeros(B, dtype=np.int32); w = np.zeros(B, dtype=np.uint32)
+        pkg._cabi.check(eng.lib.jsim_mpc_get_launch_order(eng._ctx, B, o.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)), eng._ctx)
+        return o, w
+
+    e0, l0, run0 = make(False)
+    e1, l1, run1 = make(True)
+    prev_work = None
+    for launch in range(3):
+        run0(K); run1(K)
+        order, work = order_and_work(e1)
+        assert sorted(order.tolist()) == list(range(B))
+        if prev_work is None:
+            assert np.array_equal(order, np.arange(B))               # nothing known yet: identity
+        else:
+            assert np.array_equal(order, np.argsort(-prev_work.astype(np.int64), kind="stable"))
+            assert not np.array_equal(order, np.arange(B))
+        assert work.sum() > 0 and work.max() <= K * (50 * 2 * T + 100)
+        prev_work = work
+    torch.cuda.synchronize()
+    assert torch.equal(l0.hist, l1.hist)
+    assert torch.equal(l0.x0, l1.x0) and torch.equal(l0.age, l1.age)
+    for name in ("oa", "od", "ox", "oy", "ov", "oyaw", "xref", "target_ind", "status", "n_iter", "active_mask", "di_ai", "path_len"):
+        assert torch.equal(getattr(e0, name), getattr(e1, name)), name
+    with pytest.raises(pkg._cabi.JsimError):     # the identity-order context never ranked anything
+        pkg._cabi.check(e0.lib.jsim_mpc_get_launch_order(e0._ctx, B, None, None), e0._ctx)
