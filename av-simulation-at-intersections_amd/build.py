@@ -13,11 +13,17 @@ LIB = os.path.join(_HERE, "libjsim_mpc.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # S1-S3 follow numpy's operation order; fma() is explicit where wanted
                "-fno-fast-math",
-               # Spills of these 400-500-register kernels go to scratch, not to "free" AGPRs: with the default
-               # (spill-vgpr-to-agpr on) one instantiation of the two-wave kernel was miscompiled -- correct Hessian and
-               # gradient, wrong active-set iterations, right again with this option, with machine sinking disabled, or
-               # with any instrumentation of the loop.  Register counts and speed are the same either way.
-               "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+               # Round 1 blamed a wrong result of the two-wave kernel at T = 30 on spills into "free" AGPRs.  Round 2 could
+               # not support that: at the commit in question that instantiation compiles to byte-identical ISA with and
+               # without this option, and today's library passes every test either way.  The option
+               # stays because it is what all the parity evidence was collected with; it costs nothing measurable.
+               "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
+               # MachineLICM hoists the materialisation of every 64-bit literal of the inlined sin / cos / tan polynomials
+               # (and other loop-invariant address arithmetic) out of the K-tick loop, where the values then sit in
+               # registers across the whole solve -- or, as happened, in scratch: ~20 doubles stored before the loop and
+               # reloaded in every tick.  Without it: no scratch at T = 13 / 20 / 30 (was 0 / 12 / 152-208 B), 40-60 fewer
+               # registers, 40 B (was 360 B) in the four-wave T = 40 kernel, speed within +-2 % on every configuration.
+               "-mllvm", "-disable-machine-licm"]
 
 
 def _hipcc() -> str:

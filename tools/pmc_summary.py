@@ -25,7 +25,7 @@ tr = [r for r in rows("trace", "*kernel_trace.csv") if "mpc_step" in r["Kernel_N
 dur = defaultdict(list)
 for r in tr:
     dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-name = max(dur, key=lambda k: sum(dur[k]))
+name = max(dur, key=lambda k: max(dur[k]))   # the kernel of the timed region: the one with the longest single launch
 d = sorted(dur[name])
 fused = [x for x in d if x > 0.5 * d[-1]]          # the multi-tick launches
 single = [x for x in d if x <= 0.5 * d[-1]]
@@ -52,6 +52,6 @@ for sub in ("trace",):
             out["bench_line_under_rocprof"] = json.loads(line)
             out["ticks_per_launch"] = out["bench_line_under_rocprof"]["roofline"]["ticks_per_launch"]
 st = rows("trace", "*kernel_stats.csv")
-out["kernel_stats"] = [r for r in st if "mpc_step" in r.get("Name", "") or "loop_advance" in r.get("Name", "") or "tick_" in r.get("Name", "")]
+out["kernel_stats"] = [r for r in st if any(k in r.get("Name", "") for k in ("mpc_step", "loop_", "tick_", "plan_astar", "launch_order", "obstacle_"))]
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("bench_line_under_rocprof", "kernel_stats")}, indent=1))
