@@ -154,6 +154,7 @@ def main():
         torch.cuda.synchronize(device)
 
     _route_cache = {}
+    plan_info = {}   # row f4's own measurement: the planner launch that produced the workload's routes (rank 0 reports it)
 
     def route_table(multi_lane):
         """the 12 routes of the reference's intersection() (configs 2-4) or of its two-lane scenario (config 5:
@@ -169,10 +170,15 @@ def main():
                           for sl in (1, 2) for gl in (1, 2)]
                 else:
                     qs = [PL.intersection_query(sp, tn, rad) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)]
+                PL.plan_routes(qs[:1], device=dev_index)      # untimed: module load, first use of the entry point
+                t_p0 = time.perf_counter()
                 res = PL.plan_routes(qs, device=dev_index)
+                t_p1 = time.perf_counter()
                 if any(r.status != 0 for r in res):
                     raise SystemExit(f"route planner: status {[r.status for r in res]}")
                 rs = [r.trajectory for r in res]
+                plan_info[multi_lane] = {"routes": len(qs), "wall_ms": (t_p1 - t_p0) * 1e3, "queries": qs,
+                                         "expanded": [int(r.n_expanded) for r in res], "points": int(sum(len(t) for t in rs))}
             for r in rs:
                 S.smooth_yaw_inplace(r[:, 2])
             _route_cache[multi_lane] = rs
@@ -349,8 +355,16 @@ def main():
             out["config"]["egos_cut_off_mean_at_launch_ends"] = r["cut"]
         if extra:
             out["extra"] = extra
+        pi = plan_info.get(cfg["multi_lane"])
+        if pi:
+            out["planner"] = {"what": "jsim_plan_routes (A* over motion primitives, one wavefront per route): the route table of this workload, "
+                                      "one call, host arrays in and out (uploads, search, read-back); outside the timed region",
+                              "routes": pi["routes"], "wall_ms": pi["wall_ms"], "expanded_nodes": int(sum(pi["expanded"])),
+                              "trajectory_points": pi["points"]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, r["routes"], r["batch"], T, args.cpu_seconds)
+            if pi:
+                out["planner"]["cpu_port"] = planner_cpu_baseline(pi)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -419,6 +433,30 @@ def cpu_baseline(pkg, routes, batch, T, seconds):
                        f"{n1} steps of {min(B, 32)} egos on 1 core, {na} steps of {n_all} egos on {best} threads (OpenMP over egos; the "
                        f"thread count that delivered most in a short probe over {cands}); "
                        "C port of the reference path (oracle/mpc_oracle.c, exact active-set QP); cvxpy/ECOS unavailable offline")}
+
+
+def planner_cpu_baseline(pi, max_nodes=400, budget_s=8.0):
+    """The numpy restatement of the reference's planner (oracle/planner_oracle.py) on the same route queries, one core; routes
+    whose search the GPU needed more than `max_nodes` expansions for are left out (numpy spends ~3 ms per expansion), and the
+    sample stops after `budget_s` seconds."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import planner_oracle as PO
+    import importlib
+    PL = importlib.import_module("av-simulation-at-intersections_amd").planner
+    mps = PO.make_motion_primitives()
+    radius, centres = PL.car_circles()
+    done, nodes, t0 = 0, 0, time.perf_counter()
+    for q, n in zip(pi["queries"], pi["expanded"]):
+        if n > max_nodes:
+            continue
+        orc = PO.PlannerOracle(q.start, q.goal, q.goal_box, q.tol, q.obstacles, mps, centres, radius)
+        orc.run()
+        done += 1
+        nodes += orc.n_expanded
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return {"routes": done, "wall_ms": (time.perf_counter() - t0) * 1e3, "expanded_nodes": nodes, "cores": 1, "kind": "port",
+            "sample": f"the first {done} of the workload's routes that need <= {max_nodes} expansions"}
 
 
 if __name__ == "__main__":
