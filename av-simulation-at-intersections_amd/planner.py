@@ -158,21 +158,66 @@ class PlannedRoute:
 
 
 def plan_routes(queries: Sequence[RouteQuery], L: float = 2.86, wh=WH_DEFAULT, wc=WC_DEFAULT, max_path: int = 32,
-                device: int = 0, primitives=None, node_cap: int = 16384, retry_node_cap: int = 1 << 19) -> List[PlannedRoute]:
+                device: int = 0, primitives=None, node_cap: int = 16384, retry_node_cap: int = 1 << 19, circles=None) -> List[PlannedRoute]:
     """All queries in ONE launch (one wavefront per route).  Routes whose search outgrows `node_cap` nodes (status 4) are planned
-    again, together, with `retry_node_cap` (0: no second attempt)."""
-    out = _plan(queries, L, wh, wc, max_path, device, primitives, node_cap)
+    again, together, with `retry_node_cap` (0: no second attempt).  primitives = (points [P, n, 3], total_length [P]) and
+    circles = (radius, centres [k, 2]) replace the regenerated bicycle-model set / BicycleModelDimensions' circles."""
+    out = _plan(queries, L, wh, wc, max_path, device, primitives, node_cap, circles)
     again = [i for i, r in enumerate(out) if r.status == 4]
     if again and retry_node_cap > node_cap:
-        for i, r in zip(again, _plan([queries[i] for i in again], L, wh, wc, max_path, device, primitives, retry_node_cap)):
+        for i, r in zip(again, _plan([queries[i] for i in again], L, wh, wc, max_path, device, primitives, retry_node_cap, circles)):
             out[i] = r
     return out
 
 
-def _plan(queries, L, wh, wc, max_path, device, primitives, node_cap) -> List[PlannedRoute]:
+class MotionPrimitiveSearch:
+    """Drop-in for the reference's planner class (main/lib/mp_search_ww_generic.py:26-58 constructor, :136-140 run): the same
+    arguments -- a scenario (.start, .goal_point, .goal_area with .xy1 / .xy2, .allowed_goal_theta_difference, .obstacles whose
+    .to_convex(margin) gives half-planes), car dimensions (.radius, .circle_centers), the motion primitives the CALLER holds (a
+    dict name -> object with .points (n, 3) and .total_length; iteration order = expansion order, as in the reference) and the
+    nine weights -- and run() -> (cost, path, trajectory) with path a list of (x, y, theta) tuples.  The search itself is
+    jsim_plan_routes on the GPU (one route = one wavefront; use plan_routes for many routes at once).  Like the reference,
+    run() raises Exception("No solution found.") when the open list runs empty (main/lib/a_star.py:78); debug=True (the
+    reference's matplotlib trace of the expansion) is not offered."""
+
+    def __init__(self, scenario, car_dimensions, mps, margin: float,
+                 wh_dist: float = 1.0, wh_theta: float = 2.7, wh_steering: float = 15.0, wh_obstacle: float = 0.0, wh_center: float = 0.0,
+                 wc_dist: float = 1.0, wc_steering: float = 5.0, wc_obstacle: float = 0.1, wc_center: float = 0.0, device: int = 0):
+        self._names = list(mps.keys())
+        pts = [np.asarray(mps[n].points, dtype=np.float64) for n in self._names]
+        if not pts or any(p.shape != pts[0].shape or p.ndim != 2 or p.shape[1] != 3 for p in pts):
+            raise ValueError("motion primitives must be (n, 3) arrays of one common length")
+        self._primitives = (np.stack(pts), np.array([float(mps[n].total_length) for n in self._names]))
+        self._circles = (float(car_dimensions.radius), np.asarray(car_dimensions.circle_centers, dtype=np.float64).reshape(-1, 2))
+        (x1, y1), (x2, y2) = scenario.goal_area.xy1, scenario.goal_area.xy2
+        self._query = RouteQuery(start=tuple(float(v) for v in scenario.start), goal=tuple(float(v) for v in scenario.goal_point),
+                                 goal_box=(float(x1), float(y1), float(x2), float(y2)), tol=float(scenario.allowed_goal_theta_difference),
+                                 obstacles=[np.asarray(o.to_convex(margin=margin), dtype=np.float64) for o in scenario.obstacles])
+        self._wh = (wh_dist, wh_theta, wh_steering, wh_obstacle, wh_center)
+        self._wc = (wc_dist, wc_steering, wc_obstacle, wc_center)
+        self._device = device
+        self._points_to_mp_names = {}
+        self.last = None       # the PlannedRoute of the last run (status, primitive indices, expansion count)
+
+    def run(self, debug: bool = False):
+        if debug:
+            raise NotImplementedError("debug=True (the reference's expansion trace) is not offered by the GPU planner")
+        r = plan_routes([self._query], wh=self._wh, wc=self._wc, primitives=self._primitives, circles=self._circles, device=self._device)[0]
+        self.last = r
+        if r.status == 1:
+            raise Exception("No solution found.")                    # main/lib/a_star.py:78
+        if r.status != 0:
+            raise RuntimeError(f"route planner: status {r.status} (4: node table full, 5 / 6: path longer than the output arrays)")
+        path = [tuple(float(v) for v in n) for n in r.nodes]
+        for a, b, k in zip(path[:-1], path[1:], r.prims):
+            self._points_to_mp_names[a, b] = self._names[int(k)]
+        return r.cost, path, r.trajectory
+
+
+def _plan(queries, L, wh, wc, max_path, device, primitives, node_cap, circles=None) -> List[PlannedRoute]:
     lib = _cabi.load()
     pts, length = primitives if primitives is not None else make_motion_primitives(L=L)
-    radius, centres = car_circles(L=L)
+    radius, centres = circles if circles is not None else car_circles(L=L)
     cc = [collision_points(p, centres, radius) for p in pts]
     cc_off = np.concatenate([[0], np.cumsum([len(c) for c in cc])]).astype(np.int32)
     cc_flat = np.ascontiguousarray(np.concatenate(cc, axis=0), dtype=np.float64)

@@ -147,6 +147,8 @@ def test_lib_shim_resolves_like_the_scenario_scripts_expect(tmp_path):
         "from lib.mpc import MPC, MAX_ACCEL, MPCSolutionNotFoundException\n"
         "from lib.simulation import State, WHO\n"
         "import lib.mpc_with_speed, lib.mpc_sensitivity, lib.mpc_jerk\n"
+        "from lib.mp_search_ww_generic import MotionPrimitiveSearch\n"            # main/scenarios/mpc_intersection.py:17
+        "assert MotionPrimitiveSearch.__module__ == 'av-simulation-at-intersections_amd.planner'\n"
         "assert MPC.__module__ == 'av-simulation-at-intersections_amd.mpc', MPC.__module__\n"
         "assert MAX_ACCEL == 2.0 and WHO == 'reference-side lib'\n"
         "assert lib.mpc_jerk.NX == 5 and lib.mpc_with_speed.MAX_DECEL == -5\n"

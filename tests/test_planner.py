@@ -136,3 +136,59 @@ def test_planned_routes_drive_the_mpc(pkg, oracle):
         di, ai = mpc.step(pkg.State(x=st[0], y=st[1], yaw=st[3], v=st[2]))
         st = oracle.plant_step(p, st, ai, di)
     assert reached and k > 40
+
+
+@pytest.mark.gpu
+def test_motion_primitive_search_dropin(pkg):
+    """planner.MotionPrimitiveSearch = the reference's class surface (mp_search_ww_generic.py:26-58,136-140): scenario /
+    car-dimension / primitive OBJECTS in, (cost, path, trajectory) out, `Exception("No solution found.")` on an exhausted open
+    list.  Stand-ins carry exactly the attributes the reference's constructor reads.  Checked against the golden route of the
+    reference with default weights, and against the numpy oracle with every weight non-zero (obstacle / centre terms of the
+    heuristic and of the edge cost, which the reference's scenarios leave at 0) and a caller-chosen primitive order."""
+    import planner_oracle as PO
+    from types import SimpleNamespace as NS
+    PL = pkg.planner
+    g = load_golden("planner.npz")
+    q = _queries(pkg, g)[2]
+    rad, cen = PL.car_circles()
+
+    class Obst:     # .to_convex(margin) like lib/obstacles.py:82-93; the golden query already holds margin = radius
+        def __init__(self, xy_width, xy_center): self.xy_width, self.xy_center = xy_width, xy_center
+        def to_convex(self, margin=0.0): return PL.box_halfplanes(self.xy_width, self.xy_center, margin)
+    pts, length = PL.make_motion_primitives()
+    mps = {n: NS(points=pts[k], total_length=float(length[k]), name=n) for k, n in enumerate(PL.MP_NAMES)}
+    car = NS(radius=rad, circle_centers=cen)
+    scen = NS(start=q.start, goal_point=q.goal, goal_area=NS(xy1=q.goal_box[:2], xy2=q.goal_box[2:]),
+              allowed_goal_theta_difference=q.tol, obstacles=[NS(to_convex=(lambda margin, o=o: o)) for o in q.obstacles])
+    s = PL.MotionPrimitiveSearch(scen, car, mps, margin=rad)
+    cost, path, traj = s.run(debug=False)
+    assert abs(cost - float(g["r2_cost"])) <= 1e-9 and len(path) == len(g["r2_path"]) and isinstance(path[0], tuple)
+    np.testing.assert_allclose(np.array(path), g["r2_path"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(traj, g["r2_traj"], rtol=0, atol=1e-9)
+    assert [s._points_to_mp_names[a, b] for a, b in zip(path[:-1], path[1:])] == [PL.MP_NAMES[k] for k in g["r2_prims"]]
+    with pytest.raises(NotImplementedError):
+        s.run(debug=True)
+
+    # every weight non-zero, primitives handed over in another order, real obstacle objects with a margin of their own
+    order = ["right2", "left1", "straight", "left3", "right4", "left2", "right1", "left4", "right3"]
+    mps2 = {n: mps[n] for n in order}
+    obst = [Obst((20.0, 20.0), (-20.0, 20.0)), Obst((20.0, 20.0), (20.0, 20.0)), Obst((60.0, 8.0), (0.0, -14.0))]
+    scen2 = NS(start=(-25.0, -3.0, 0.0), goal_point=(3.0, 30.0, np.pi / 2), goal_area=NS(xy1=(1.0, 29.0), xy2=(5.0, 31.0)),
+               allowed_goal_theta_difference=np.pi / 16, obstacles=obst)
+    w = dict(wh_dist=1.1, wh_theta=2.0, wh_steering=12.0, wh_obstacle=0.7, wh_center=0.05, wc_dist=0.9, wc_steering=4.0, wc_obstacle=0.3, wc_center=0.02)
+    s2 = PL.MotionPrimitiveSearch(scen2, car, mps2, margin=0.5, **w)
+    cost2, path2, traj2 = s2.run()
+    omps = [(n, np.asarray(mps2[n].points), mps2[n].total_length) for n in order]
+    orc = PO.PlannerOracle(scen2.start, scen2.goal_point, (1.0, 29.0, 5.0, 31.0), np.pi / 16, [o.to_convex(0.5) for o in obst], omps, cen, rad,
+                           wh=(w["wh_dist"], w["wh_theta"], w["wh_steering"], w["wh_obstacle"], w["wh_center"]),
+                           wc=(w["wc_dist"], w["wc_steering"], w["wc_obstacle"], w["wc_center"]))
+    c3, p3, t3 = orc.run()
+    assert [order[k] for k in s2.last.prims] == [order[k] for k in orc.prim_sequence(p3)]
+    assert abs(cost2 - c3) <= 1e-9 * max(1.0, abs(c3))
+    np.testing.assert_allclose(traj2, t3, rtol=0, atol=1e-9)
+
+    # nothing reachable: the reference's exception text
+    walled = NS(start=(0.0, 0.0, 0.0), goal_point=(60.0, 0.0, 0.0), goal_area=NS(xy1=(59.0, -1.0), xy2=(61.0, 1.0)),
+                allowed_goal_theta_difference=np.pi / 16, obstacles=[Obst((49.0, 100.0), (25.5, 0.0))])
+    with pytest.raises(Exception, match="No solution found"):
+        PL.MotionPrimitiveSearch(walled, car, mps, margin=0.0).run()
