@@ -192,3 +192,66 @@ def test_motion_primitive_search_dropin(pkg):
                 allowed_goal_theta_difference=np.pi / 16, obstacles=[Obst((49.0, 100.0), (25.5, 0.0))])
     with pytest.raises(Exception, match="No solution found"):
         PL.MotionPrimitiveSearch(walled, car, mps, margin=0.0).run()
+
+
+def _stored_queries(pkg, g):
+    """Route queries straight from the fixture's arrays (tests/golden/planner_envs.npz: scenario objects of the reference's
+    other builders -- roundabout, T-intersection -- dumped as data; nothing of those builders is restated)."""
+    PL = pkg.planner
+    qs = []
+    for i in range(int(g["n_routes"])):
+        off = g[f"r{i}_hp_off"]
+        obst = [g[f"r{i}_hp"][off[k]:off[k + 1]] for k in range(len(off) - 1)]
+        qs.append(PL.RouteQuery(start=tuple(g[f"r{i}_start"]), goal=tuple(g[f"r{i}_goal"]), goal_box=tuple(g[f"r{i}_goal_box"]),
+                                tol=float(g[f"r{i}_tol"]), obstacles=obst))
+    return qs
+
+
+def test_planner_oracle_on_the_references_other_scenarios(pkg):
+    import planner_oracle as PO
+    g = load_golden("planner_envs.npz")
+    n = int(g["n_routes"])
+    assert n >= 30 and len({str(s).split("/")[0] for s in g["labels"]}) >= 2      # roundabout, t_intersection
+    mps = PO.make_motion_primitives()
+    found = none = 0
+    for i, q in enumerate(_stored_queries(pkg, g)):
+        if int(g[f"r{i}_n_expanded"]) > 700:          # (numpy spends ~3 ms per expansion; the long searches are the GPU test's)
+            continue
+        orc = PO.PlannerOracle(q.start, q.goal, q.goal_box, q.tol, q.obstacles, mps, g["circle_centers"], float(g["radius"]))
+        if np.isnan(float(g[f"r{i}_cost"])):          # the reference's search ran out of open nodes: so must the oracle's, as late
+            with pytest.raises(Exception, match="No solution found"):
+                orc.run()
+            none += 1
+        else:
+            cost, path, traj = orc.run()
+            assert cost == float(g[f"r{i}_cost"]) and np.array_equal(np.array(path), g[f"r{i}_path"]) and np.array_equal(traj, g[f"r{i}_traj"])
+            assert orc.prim_sequence(path) == list(g[f"r{i}_prims"])
+            found += 1
+        assert orc.n_expanded == int(g[f"r{i}_n_expanded"])
+    assert found >= 20 and none >= 4
+
+
+@pytest.mark.gpu
+def test_hip_planner_on_the_references_other_scenarios(pkg):
+    """Every stored query of the roundabout (both sizes, U-turns included) and the T-intersection in ONE launch: the reference's
+    route each time -- and where the reference's open list ran empty after 600 ... 11k expansions ("No solution found."), status 1
+    after as many."""
+    g = load_golden("planner_envs.npz")
+    qs = _stored_queries(pkg, g)
+    res = pkg.planner.plan_routes(qs, max_path=64)
+    none = worst = 0
+    for i, r in enumerate(res):
+        label = str(g["labels"][i])
+        ne = int(g[f"r{i}_n_expanded"])
+        assert abs(r.n_expanded - ne) <= max(1, ne // 50), (label, r.n_expanded, ne)
+        if np.isnan(float(g[f"r{i}_cost"])):
+            assert r.status == 1 and len(r.trajectory) == 0, (label, r.status)
+            none += 1
+            worst = max(worst, ne)
+            continue
+        assert r.status == 0, (label, r.status)
+        assert list(r.prims) == list(g[f"r{i}_prims"]), label
+        assert abs(r.cost - float(g[f"r{i}_cost"])) <= 1e-9 * max(1.0, abs(float(g[f"r{i}_cost"]))), label
+        np.testing.assert_allclose(r.nodes, g[f"r{i}_path"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r.trajectory, g[f"r{i}_traj"], rtol=0, atol=1e-9)
+    assert none >= 10 and worst >= 10000
