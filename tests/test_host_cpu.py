@@ -128,6 +128,8 @@ def test_integration_doc_struct_matches_binding(pkg):
         hnames += [re.sub(r"\[\d+\]", "", v).strip() for v in decl.split(",")]
     assert hnames == [n for n, _, _ in fields]
     assert f"jsim_abi_version() == {pkg._cabi.ABI_VERSION}" in doc
+    # the table of entry points names every export of the library (and the header declares each: test_cabi_exports)
+    assert [e for e in pkg._cabi.EXPORTS if f"`{e}`" not in doc and f"`{e}` " not in doc and e not in doc] == []
 
 
 def test_lib_shim_resolves_like_the_scenario_scripts_expect(tmp_path):
