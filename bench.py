@@ -92,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--routes", choices=("planner", "synthetic"), default="planner",
                     help="planner (default): the route table is planned on the GPU (jsim_plan_routes: A* over motion primitives on the "
                          "reference's intersection geometry, 12 routes / 48 two-lane routes, untimed set-up); synthetic: idealised arcs")
+    ap.add_argument("--respawn", choices=("initial", "start"), default="initial",
+                    help="where an ego that reached its goal (or timed out) re-enters: its own random initial state, or the first point of "
+                         "its route at standstill like the reference's scenarios start their vehicle")
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the config 4 / config 5 per-rank shares")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
@@ -200,6 +203,10 @@ def main():
         else:
             loop = pkg.ClosedLoop(eng, x0, hist_cap=K + W + 8, max_age=400)
             tick, run = loop.tick, loop.run
+        if args.respawn == "start":   # State(x, y, yaw of the route's first point, v = 0): main/scenarios/mpc_intersection.py:78-79
+            first = np.array([[routes[p][0, 0], routes[p][0, 1], 0.0, routes[p][0, 2]] for p in batch.path_id])
+            loop.x0_spawn.copy_(torch.from_numpy(first).to(device))
+            loop.target_spawn.zero_()
 
         for _ in range(W):          # warm-up (untimed)
             tick()
@@ -336,6 +343,9 @@ def main():
                        "routes": (("48 two-lane routes" if cfg["multi_lane"] else "12 intersection routes") +
                                   (" planned on the GPU (A* over motion primitives, the reference's scenario geometry)" if args.routes == "planner"
                                    else ", synthetic arcs")),
+                       "respawn": ("an ego that reaches its goal or times out (400 ticks) re-enters in its own initial state (SURVEY 8d's distribution: "
+                                   "lateral / heading / speed perturbations keep being injected)" if args.respawn == "initial" else
+                                   "an ego that reaches its goal or times out re-enters at the first point of its route at standstill"),
                        "launch": {"fused": f"fused closed loop, {r['chunk']} ticks per launch", "graph": "hipGraph",
                                   "eager": "eager"}[r["mode"]], "parallelism": f"ego-shard x{world}",
                        "mean_active_set_iters": round(r["mean_iter"], 2), "failed_egos_last_tick": r["n_fail"],
