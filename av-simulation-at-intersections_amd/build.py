@@ -22,7 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # (and other loop-invariant address arithmetic) out of the K-tick loop, where the values then sit in
                # registers across the whole solve -- or, as happened, in scratch: ~20 doubles stored before the loop and
                # reloaded in every tick.  Without it: no scratch at T = 13 / 20 / 30 (was 0 / 12 / 152-208 B), 40-60 fewer
-               # registers, 12 B (was 360 B) in the four-wave T = 40 kernel, speed within +-2 % on every configuration.
+               # registers, 0 B (was 360 B) in the four-wave T = 40 kernel, speed within +-2 % on every configuration.
                "-mllvm", "-disable-machine-licm"]
 
 

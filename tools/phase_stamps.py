@@ -24,7 +24,7 @@ if not os.environ.get("JSIM_STAMPS_LIB"):   # (JSIM_STAMPS_LIB: a -DJSIM_STAMPS 
 pkg._cabi.LIB_PATH = lib
 pkg._cabi._lib = None
 S = pkg.synth
-routes = S.make_route_table()
+routes = S.make_route_table(multi_lane=os.environ.get("JSIM_MULTI_LANE") == "1")
 for r in routes:
     S.smooth_yaw_inplace(r[:, 2])
 batch = S.make_ego_batch(routes, B, T, seed=1)
@@ -66,4 +66,9 @@ A = np.vstack([np.ones_like(itacc), itacc]).T
 for nme, y in (("active-set loop", acc[:, 9]), ("whole step", tot), ("u0 phase", acc[:, 8])):
     coef, *_ = np.linalg.lstsq(A, y, rcond=None)
     print(f"  fit {nme:16s} = {coef[0]:9.0f} + {coef[1]:7.0f} * n_iter cycles")
-per_ego = tot.reshape(-1, ok.sum()) if False else None
+# the same sections for the solves with the most iterations (the egos that set the launch time)
+big = itacc >= np.percentile(itacc, 99.5)
+if big.sum():
+    print(f"solves with n_iter >= {np.percentile(itacc, 99.5):.0f} ({int(big.sum())} solves, mean n_iter {itacc[big].mean():.1f}, mean step {tot[big].mean():.0f} cycles):")
+    for k, nme in enumerate(gn):
+        print(f"  {nme:20s} {gacc[big, k].sum() / itacc[big].sum():8.0f} cyc/iter   {100 * gacc[big, k].sum() / gacc[big].sum():5.1f} %")
