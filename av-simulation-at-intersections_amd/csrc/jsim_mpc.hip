@@ -1811,6 +1811,15 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     if (!start || !goal || !goal_box || !tol || !hp_off || !route_obs_off || !mp_pts || !mp_len || !cc_pts || !cc_off || !wh || !wc ||
         !status || !cost || !n_prims || !prims || !nodes || !traj || !n_expanded || (n_obs_total > 0 && !hp))
         return fail(nullptr, -22, "jsim_plan_routes: null argument");
+    // the offset tables index device arrays from inside the kernel: they must be what they claim to be
+    for (int k = 0; k < n_obs_total; ++k)
+        if (hp_off[k] < 0 || hp_off[k + 1] < hp_off[k]) return fail(nullptr, -22, "jsim_plan_routes: hp_off is not non-decreasing at %d", k);
+    if (hp_off[0] != 0) return fail(nullptr, -22, "jsim_plan_routes: hp_off[0] = %d", hp_off[0]);
+    for (int k = 0; k < n_routes; ++k)
+        if (route_obs_off[k] < 0 || route_obs_off[k + 1] < route_obs_off[k] || route_obs_off[k + 1] > n_obs_total)
+            return fail(nullptr, -22, "jsim_plan_routes: route_obs_off[%d..%d] = %d, %d with %d obstacles", k, k + 1, route_obs_off[k], route_obs_off[k + 1], n_obs_total);
+    for (int k = 0; k < n_prim; ++k)
+        if (cc_off[k] < 0 || cc_off[k + 1] < cc_off[k]) return fail(nullptr, -22, "jsim_plan_routes: cc_off is not non-decreasing at %d", k);
     int ndev = 0;
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -19, "jsim_plan_routes: device %d of %d", device_id, ndev);
@@ -1819,7 +1828,6 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     int hash_cap = 128;
     while (hash_cap < 2 * cap) hash_cap <<= 1;
     const size_t n_hp = (size_t)hp_off[n_obs_total], n_cc = (size_t)cc_off[n_prim];
-    struct Buf { void *p = nullptr; };
     std::vector<void *> owned;
     auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes ? bytes : 8) != hipSuccess) return nullptr; owned.push_back(q); return q; };
     auto put = [&](const void *src, size_t bytes) -> void * {

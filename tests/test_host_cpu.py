@@ -266,3 +266,39 @@ def test_gather_entry_points_argument_errors_without_gpu(pkg):
     assert lib.jsim_comm_init(None, None, 1, 0) < 0
     assert lib.jsim_comm_unique_id(None) < 0
     assert lib.jsim_comm_destroy(None) < 0
+
+
+def test_plan_routes_argument_errors_without_gpu(pkg):
+    """jsim_plan_routes checks sizes, null pointers and its offset tables on the host, before anything touches a device."""
+    import ctypes as C
+    lib = pkg._cabi.load()
+    PL = pkg.planner
+    pts, length = PL.make_motion_primitives()
+    rad, cen = PL.car_circles()
+    cc = np.concatenate([PL.collision_points(p, cen, rad) for p in pts], axis=0)
+    cc_off = np.concatenate([[0], np.cumsum([len(PL.collision_points(p, cen, rad)) for p in pts])]).astype(np.int32)
+    q = PL.intersection_query(1, 1, rad)
+    hp = np.ascontiguousarray(np.concatenate(q.obstacles, axis=0))
+    hp_off = np.concatenate([[0], np.cumsum([len(o) for o in q.obstacles])]).astype(np.int32)
+    r_off = np.array([0, len(q.obstacles)], dtype=np.int32)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    start, goal, box, tol = f64([q.start]), f64([q.goal]), f64([q.goal_box]), f64([q.tol])
+    wh, wc = f64(PL.WH_DEFAULT), f64(PL.WC_DEFAULT)
+    mp, ml = f64(pts), f64(length)
+    max_path = 8
+    status = np.zeros(1, np.int32); cost = np.zeros(1); n_prims = np.zeros(1, np.int32); prims = np.zeros((1, max_path), np.int32)
+    nodes = np.zeros((1, max_path + 1, 3)); traj = np.zeros((1, max_path * 60, 3)); n_exp = np.zeros(1, np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+
+    def call(hp_off_=hp_off, r_off_=r_off, cc_off_=cc_off, n_prim=9, node_cap=4096, start_=start):
+        return lib.jsim_plan_routes(0, 1, p(start_) if start_ is not None else None, p(goal), p(box), p(tol), p(hp), p(hp_off_), len(hp_off) - 1,
+                                    p(r_off_), p(mp), p(ml), n_prim, 61, p(cc), p(cc_off_), p(wh), p(wc), max_path, node_cap, p(status), p(cost),
+                                    p(n_prims), p(prims), p(nodes), p(traj), p(n_exp))
+    assert call(n_prim=0) == -22 and b"bad sizes" in lib.jsim_last_error(None)
+    assert call(node_cap=8) == -22
+    assert call(start_=None) == -22 and b"null argument" in lib.jsim_last_error(None)
+    bad = hp_off.copy(); bad[2] = bad[1] - 1
+    assert call(hp_off_=bad) == -22 and b"hp_off" in lib.jsim_last_error(None)
+    assert call(r_off_=np.array([0, len(q.obstacles) + 1], dtype=np.int32)) == -22 and b"route_obs_off" in lib.jsim_last_error(None)
+    bad = cc_off.copy(); bad[3] = bad[2] - 1
+    assert call(cc_off_=bad) == -22 and b"cc_off" in lib.jsim_last_error(None)
