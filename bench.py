@@ -235,11 +235,13 @@ def main():
         # ---- timed region: exactly K ticks.  HIP events are recorded on the stream the kernels are launched on (the
         # engine passes torch's current stream of this device to the C-ABI, and torch.cuda.Event records on that stream)
         evs, ncut = [], []
+        pre_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K // chunk if mode == "fused" else 0)]
+        for ea, eb in pre_evs:        # (event objects are created lazily on first record: not inside the timed region)
+            ea.record(); eb.record()
         sync_all()
         t0 = time.perf_counter()
         if mode == "fused":         # closed loop on the device: `chunk` ticks per launch, egos never wait for each other
-            for _ in range(K // chunk):
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for ea, eb in pre_evs:
                 if cfg["scenario"]:
                     sc.obst.reset()         # a 128-byte device-to-device copy on the launch stream
                     ncut.append((eng.path_len < eng.full_len).sum())     # of the previous launch's last tick (no sync here)
