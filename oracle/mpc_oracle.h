@@ -27,12 +27,20 @@
  *   S1-S3, S5 (reference window, rollout, linearisation, deviation/goal, plant): PINNED by golden
  *     vectors generated in the build container by importing the reference's own Python modules
  *     (tests/golden/make_golden.py -> the .npz files under tests/golden/).
- *   S4 (the QP solve): the reference calls cvxpy -> ECOS (main/lib/mpc.py:196-197); neither is
- *     installed/pinned anywhere and the reference holds no golden vectors for it, so against ECOS
- *     itself this stage is "PARITY UNPINNED".  The QP is strictly convex (lambda_min(H) >= 2*min(R) > 0),
- *     so its optimum is unique; the oracle solves it exactly (Goldfarb-Idnani dual active set) and is
- *     checked by KKT residuals, by an independent numpy restatement of the sparse (uncondensed) QP the
- *     reference hands to cvxpy, and by scipy cross-checks (tests/test_oracle_qp.py).
+ *   S4, assembly (which cost terms over which t, the reaches_end switches, the constraint list and its order,
+ *     main/lib/mpc.py:141-194): PINNED since round 3 by the reference's OWN `_linear_mpc_control`, executed unmodified
+ *     under a recording stand-in for the eight cvxpy names it touches (tests/golden/cvxpy_recorder.py).  The sparse
+ *     problem it emitted -- 4 x 150 whole MPC.step calls committed as tests/golden/ref_qp_T*.npz, 4 x 1000 more compared
+ *     at generation time (ref_qp_sweep.json), fresh ones in tests/test_ref_qp_live.py -- equals this oracle's condensed
+ *     (H, g, G, h) after generic elimination of the states to <= 1e-12 (g: 1e-11), row for row in the emitted order,
+ *     and the reference's S5 lines (:199-211, :298-303) run on the optimum give this oracle's outputs (u* <= 2e-9,
+ *     integers and xref bit for bit, active sets identical wherever the multipliers are unique).
+ *   S4, the numbers ECOS returns: the reference calls cvxpy -> ECOS (main/lib/mpc.py:196-197); neither is
+ *     installed/pinned anywhere and the reference holds no golden vectors for it, so against ECOS's own
+ *     stopping tolerance (1e-8, OPTIMAL_INACCURATE accepted) this stage stays "PARITY UNPINNED".  The QP is
+ *     strictly convex (lambda_min(H) >= 2*min(R) > 0), so its optimum is unique; the oracle solves it exactly
+ *     (Goldfarb-Idnani dual active set); the stand-in's optimum of the emitted problem comes from an unrelated
+ *     solver (null-space elimination + Mehrotra interior point + KKT polish) and agrees to <= 2e-9.
  */
 #ifndef MPC_ORACLE_H
 #define MPC_ORACLE_H

@@ -48,6 +48,8 @@ def test_hip_step_against_reference_step(pkg, routes, T):
     # the condensed QP the kernel built vs the reference's emitted problem (x eliminated by a generic dense solve), a sample
     Hk, gk = dbg["H"].cpu().numpy(), dbg["g"].cpu().numpy()
     for i in list(range(0, B, 7)) + [B - 1]:
+        if not ok[i]:
+            continue                                  # an infeasible start leaves the kernel before the QP is built
         P, q, c0, A, b, G, h = RT.emitted_problem(g, i)
         Hr, gr, Gr, hr, Phi, phi = QS.condense(P, q, A, b, G, h, T)
         assert np.abs(np.tril(Hk[i]) - np.tril(Hr)).max() <= 1e-9 * np.abs(Hr).max()
