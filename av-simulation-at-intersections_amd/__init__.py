@@ -18,3 +18,4 @@ from . import mpc_with_speed  # noqa: F401
 from . import mpc_sensitivity  # noqa: F401
 from . import mpc_jerk  # noqa: F401
 from . import planner  # noqa: F401
+from . import workloads  # noqa: F401

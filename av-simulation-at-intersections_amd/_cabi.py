@@ -31,7 +31,7 @@ class JsimCfg(C.Structure):
 
 EXPORTS = (
     "jsim_abi_version", "jsim_last_error", "jsim_mpc_create", "jsim_mpc_destroy", "jsim_mpc_set_paths",
-    "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance", "jsim_mpc_run_ticks", "jsim_mpc_set_launch_order", "jsim_mpc_get_launch_order",
+    "jsim_mpc_step", "jsim_mpc_step_debug", "jsim_plant_step", "jsim_loop_advance", "jsim_mpc_run_ticks", "jsim_mpc_set_launch_order", "jsim_mpc_get_launch_order", "jsim_mpc_iter_totals",
     "jsim_loop_set_geometry", "jsim_loop_set_obstacle_geometry", "jsim_loop_predict_obstacles", "jsim_loop_pre_tick",
     "jsim_mpc_set_path_speed", "jsim_mpc_set_speed_cutoff", "jsim_mpc_update_cfg", "jsim_mpc_set_ego_config", "jsim_loop_obstacles",
     "jsim_mpc_xref_deviation_goal", "jsim_loop_run_scenario",
@@ -96,6 +96,8 @@ def load() -> C.CDLL:
     lib.jsim_mpc_set_launch_order.argtypes = [vp, i32]
     lib.jsim_mpc_get_launch_order.restype = C.c_int
     lib.jsim_mpc_get_launch_order.argtypes = [vp, i32, vp, vp]
+    lib.jsim_mpc_iter_totals.restype = C.c_int
+    lib.jsim_mpc_iter_totals.argtypes = [vp, i32, vp, i32]
     lib.jsim_mpc_run_ticks.restype = C.c_int
     lib.jsim_mpc_run_ticks.argtypes = [vp, i32, i32] + [vp] * 19 + [i32, vp, vp, i32, vp, vp]
     lib.jsim_loop_run_scenario.restype = C.c_int

@@ -1059,30 +1059,33 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 }
 
 #include "mpc_step_reg.inc"
-#include "mpc_step_reg2.inc"
+#include "reg_common.inc"
 #include "mpc_step_reg4.inc"
 
-// horizons with a register-resident kernel: 3T+1 <= 64 lanes -> one wavefront per ego; T = 30 / 40 -> two wavefronts per ego
-#ifndef JSIM_REG2_T_A
-#define JSIM_REG2_T_A 30
-#endif
-#ifndef JSIM_REG2_T_B
-#define JSIM_REG2_T_B 40
-#endif
-static bool has_reg_kernel(int T) { return T == 13 || T == 20 || T == JSIM_REG2_T_A || T == JSIM_REG2_T_B; }
+// horizons with a register-resident kernel: 13 / 20 (3T+1 <= 64 lanes: one wavefront per ego, every row stored), 30 (one wavefront,
+// virtual speed rows), 40 (four wavefronts, two lanes per row)
+static bool has_reg_kernel(int T) { return T == 13 || T == 20 || T == 30 || T == 40; }
 static bool has_fused_glue(int T) { return has_reg_kernel(T); }
 
 static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
 {
     static const PreK none = {};
-#ifdef JSIM_DEV_ONLY_REG2_30 /* development builds: only the two-wave kernel at T = 30 (the instantiation of DESIGN.md section 5, fact 4) */
-    if (T == 30) hipLaunchKernelGGL((mpc_step_reg2_kernel<30, false>), dim3(B), dim3(128), 0, s, P, K, none);
-    (void)Q;
-    return;
-#elif defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
+#if defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
     if (T == 40) {
         if (Q) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
         else hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
+    }
+    return;
+#elif defined(JSIM_DEV_ONLY_T30) /* development builds: only the T = 30 one-wave kernel */
+    if (T == 30) {
+        if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
+    }
+    return;
+#elif defined(JSIM_DEV_ONLY_T20) /* development builds: only the T = 20 one-wave kernel */
+    if (T == 20) {
+        if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else hipLaunchKernelGGL((mpc_step_reg_kernel<20, false>), dim3(B), dim3(64), 0, s, P, K, none);
     }
     return;
 #else
@@ -1090,25 +1093,13 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
         if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
-#ifdef JSIM_T40_TWO_WAVE
-        else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_B, true>), dim3(B), dim3(128), 0, s, P, K, *Q);
-#else
         else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
-#endif
         return;
     }
     if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false>), dim3(B), dim3(64), 0, s, P, K, none);
     else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false>), dim3(B), dim3(64), 0, s, P, K, none);
-#ifdef JSIM_T30_TWO_WAVE
-    else if (T == JSIM_REG2_T_A) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_A, false>), dim3(B), dim3(128), 0, s, P, K, none);
-#else
     else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
-#endif
-#ifdef JSIM_T40_TWO_WAVE
-    else if (T == JSIM_REG2_T_B) hipLaunchKernelGGL((mpc_step_reg2_kernel<JSIM_REG2_T_B, false>), dim3(B), dim3(128), 0, s, P, K, none);
-#else
     else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
-#endif
 #endif
 }
 
@@ -1274,6 +1265,8 @@ struct jsim_ctx {
     void *comm;         // ncclComm_t of jsim_comm_init (RCCL), or NULL
     int *d_order;       // launch order of the fused closed-loop launches (prepare_launch_order) ..
     unsigned *d_work;   // .. and the per-ego iteration count of the previous launch it is derived from
+    unsigned long long *d_iters; // per-ego running totals of active-set iterations over the fused launches (jsim_mpc_iter_totals)
+    int iters_cap;
     int order_cap;
     int order_mode;     // 0: from the environment (default on), 1: on, -1: off (jsim_mpc_set_launch_order)
     int use_reg_kernel; // 1: register-resident fast path available for this T (and not disabled)
@@ -1307,10 +1300,16 @@ static int fail(jsim_ctx *ctx, int code, const char *fmt, ...)
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
+    hipError_t err = hipSuccess; // a failed hipGetDevice / hipSetDevice: the entry point must not carry on on the caller's device
     explicit DeviceGuard(int dev)
     {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
     }
+    bool ok() const { return err == hipSuccess; }
     ~DeviceGuard()
     {
         if (switched) (void)hipSetDevice(prev);
@@ -1318,6 +1317,11 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
+
+#define JSIM_GUARD_OK(ctx_)                                                                                   \
+    do {                                                                                                       \
+        if (!dev_guard.ok()) return fail(ctx_, -5, "switching to the context's device failed: %s", hipGetErrorString(dev_guard.err)); \
+    } while (0)
 
 extern "C" int jsim_abi_version(void) { return JSIM_ABI_VERSION; }
 
@@ -1340,6 +1344,7 @@ extern "C" int jsim_mpc_create(const jsim_cfg *cfg, int device_id, jsim_ctx **ou
     const size_t lds_bytes = jsim_lds_doubles(cfg->T, cfg->nx == 5) * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(nullptr, -22, "jsim_mpc_create: T=%d needs %zu B of LDS (> 160 KiB)", cfg->T, lds_bytes);
     DeviceGuard dev_guard(device_id);   // the caller's current device is left as it was
+    JSIM_GUARD_OK(nullptr);
     // dynamic LDS above the 64 KiB default has to be granted per kernel; done once here so that the step call
     // itself is pure launches (it may be captured into a hipGraph)
     HIP_TRY(nullptr, hipFuncSetAttribute((const void *)mpc_step_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1381,7 +1386,7 @@ extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->comm) (void)jsim_comm_destroy(ctx);
-    DeviceGuard dev_guard(ctx->device);
+    DeviceGuard dev_guard(ctx->device);   // (a failed switch still frees: hipFree takes the pointers' own device)
     free_paths(ctx);
     if (ctx->d_pred_cc) (void)hipFree(ctx->d_pred_cc);
     if (ctx->d_get_all) (void)hipFree(ctx->d_get_all);
@@ -1390,6 +1395,7 @@ extern "C" void jsim_mpc_destroy(jsim_ctx *ctx)
     if (ctx->d_pred_bc) (void)hipFree(ctx->d_pred_bc);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_iters) (void)hipFree(ctx->d_iters);
     delete ctx;
 }
 
@@ -1416,6 +1422,7 @@ extern "C" int jsim_mpc_set_paths(jsim_ctx *ctx, const double *cx, const double 
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_paths: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (!cx || !cy || !cyaw || !path_off || n_paths < 1) return fail(ctx, -22, "jsim_mpc_set_paths: bad argument");
     if (path_off[0] != 0) return fail(ctx, -22, "jsim_mpc_set_paths: path_off[0] must be 0");
     for (int i = 0; i < n_paths; ++i)
@@ -1508,6 +1515,33 @@ static int prepare_launch_order(jsim_ctx *ctx, int B, hipStream_t s, TickP &K)
     return 0;
 }
 
+// Per-ego running totals of active-set iterations, added to by every fused launch (one 8-byte update per ego and tick).
+static int prepare_iter_totals(jsim_ctx *ctx, int B, hipStream_t s, TickP &K)
+{
+    K.iters = nullptr;
+    if (ctx->iters_cap < B) {
+        if (ctx->d_iters) (void)hipFree(ctx->d_iters);
+        ctx->d_iters = nullptr; ctx->iters_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_iters, sizeof(unsigned long long) * (size_t)B));
+        ctx->iters_cap = B;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_iters, 0, sizeof(unsigned long long) * (size_t)B, s));
+    }
+    K.iters = ctx->d_iters;
+    return 0;
+}
+
+extern "C" int jsim_mpc_iter_totals(jsim_ctx *ctx, int32_t B, uint64_t *totals, int32_t reset)
+{
+    if (!ctx) return fail(nullptr, -22, "jsim_mpc_iter_totals: null ctx");
+    DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
+    if (B <= 0 || B > ctx->iters_cap) return fail(ctx, -22, "jsim_mpc_iter_totals: B=%d, but the fused launches of this context had at most %d egos", B, ctx->iters_cap);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (totals) HIP_TRY(ctx, hipMemcpy(totals, ctx->d_iters, sizeof(uint64_t) * (size_t)B, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemset(ctx->d_iters, 0, sizeof(unsigned long long) * (size_t)ctx->iters_cap));
+    return 0;
+}
+
 extern "C" int jsim_mpc_set_launch_order(jsim_ctx *ctx, int32_t enabled)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_launch_order: null ctx");
@@ -1519,6 +1553,7 @@ extern "C" int jsim_mpc_get_launch_order(jsim_ctx *ctx, int32_t B, int32_t *orde
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_get_launch_order: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B <= 0 || B > ctx->order_cap) return fail(ctx, -22, "jsim_mpc_get_launch_order: B=%d, but the last ordered launch had %d egos", B, ctx->order_cap);
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (order) HIP_TRY(ctx, hipMemcpy(order, ctx->d_order, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
@@ -1533,6 +1568,7 @@ static int launch_step(jsim_ctx *ctx, int32_t B, const double *x0, const int32_t
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_step: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0) return fail(ctx, -22, "jsim_mpc_step: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status)
@@ -1591,6 +1627,7 @@ extern "C" int jsim_plant_step(jsim_ctx *ctx, int32_t B, double *x0, const doubl
 {
     if (!ctx) return fail(nullptr, -22, "jsim_plant_step: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0) return fail(ctx, -22, "jsim_plant_step: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !oa || !od || !status || !di_ai) return fail(ctx, -22, "jsim_plant_step: null device pointer");
@@ -1607,6 +1644,7 @@ extern "C" int jsim_mpc_xref_deviation_goal(jsim_ctx *ctx, int32_t B, const doub
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_xref_deviation_goal: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0) return fail(ctx, -22, "jsim_mpc_xref_deviation_goal: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !path_id || !path_len || !target_ind || (deviation && (!ox || !oy)))
@@ -1627,6 +1665,7 @@ extern "C" int jsim_loop_advance(jsim_ctx *ctx, int32_t B, double *x0, double *o
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_advance: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0) return fail(ctx, -22, "jsim_loop_advance: B=%d", B);
     if (B == 0) return 0;
     if (!x0 || !oa || !od || !status || !di_ai || !target_ind || !path_id || !path_len || !x0_spawn || !target_spawn || !age)
@@ -1664,6 +1703,7 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_run_ticks: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0 || n_ticks < 0) return fail(ctx, -22, "jsim_mpc_run_ticks: B=%d n_ticks=%d", B, n_ticks);
     if (B == 0 || n_ticks == 0) return 0;
     if (!x0 || !path_id || !path_len || !speed || !target_ind || !oa || !od || !status || !di_ai || !x0_spawn ||
@@ -1698,6 +1738,7 @@ extern "C" int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, dou
     K.x0w = x0; K.di_ai = di_ai; K.x0_spawn = x0_spawn; K.target_spawn = (const long long *)target_spawn; K.age = age;
     K.hist = hist; K.tick = tick; K.n_respawn = (unsigned long long *)n_respawn;
     if (int rc_ = prepare_launch_order(ctx, B, s, K)) return rc_;
+    if (int rc_ = prepare_iter_totals(ctx, B, s, K)) return rc_;
     launch_reg(c.T, B, s, P, K);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());
@@ -1759,6 +1800,7 @@ extern "C" int jsim_comm_init(jsim_ctx *ctx, const void *id128, int32_t n_ranks,
     if (ctx->comm) return fail(ctx, -17, "jsim_comm_init: this context already has a communicator");
     if (int rc = rccl_load(ctx)) return rc;
     DeviceGuard dev_guard(ctx->device); // ncclCommInitRank binds the communicator to the current device
+    JSIM_GUARD_OK(ctx);
     JsimNcclId id;
     memcpy(&id, id128, sizeof(id));
     void *comm = nullptr;
@@ -1777,6 +1819,7 @@ extern "C" int jsim_mpc_gather(jsim_ctx *ctx, void *comm, const void *local, voi
     if (!local || !out) return fail(ctx, -22, "jsim_mpc_gather: null device pointer");
     if (int rc = rccl_load(ctx)) return rc;
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     const int r = g_rccl.AllGather(local, out, bytes_per_rank, /* ncclChar */ 0, c, (hipStream_t)stream);
     if (r) return fail(ctx, -5, "ncclAllGather: %s", g_rccl.GetErrorString(r));
     return 0;
@@ -1787,6 +1830,7 @@ extern "C" int jsim_comm_destroy(jsim_ctx *ctx)
     if (!ctx) return fail(nullptr, -22, "jsim_comm_destroy: null ctx");
     if (!ctx->comm) return 0;
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     const int r = g_rccl.h ? g_rccl.CommDestroy(ctx->comm) : 0;
     ctx->comm = nullptr;
     if (r) return fail(ctx, -5, "ncclCommDestroy: %s", g_rccl.GetErrorString(r));
@@ -1824,6 +1868,7 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -19, "jsim_plan_routes: device %d of %d", device_id, ndev);
     DeviceGuard dev_guard(device_id);
+    JSIM_GUARD_OK(nullptr);
     const int R = n_routes, cap = node_cap, seg = n_pts - 1;
     int hash_cap = 128;
     while (hash_cap < 2 * cap) hash_cap <<= 1;
@@ -1899,6 +1944,7 @@ extern "C" int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_set_geometry: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (!(radius > 0)) return fail(ctx, -22, "jsim_loop_set_geometry: radius must be positive");
     ctx->cc0 = cc_front; ctx->cc1 = cc_rear; ctx->col_radius = radius; ctx->have_geom = 1;
     if (!ctx->have_ogeom) { ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = ctx->cfg.L; }
@@ -1911,6 +1957,7 @@ extern "C" int jsim_loop_set_obstacle_geometry(jsim_ctx *ctx, double cc_front, d
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_set_obstacle_geometry: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (!(radius > 0) || !(wheelbase > 0)) return fail(ctx, -22, "jsim_loop_set_obstacle_geometry: radius and wheelbase must be positive");
     ctx->occ0 = cc_front; ctx->occ1 = cc_rear; ctx->ocol_radius = radius; ctx->oL = wheelbase; ctx->have_ogeom = 1;
     return 0;
@@ -1921,6 +1968,7 @@ extern "C" int jsim_loop_predict_obstacles(jsim_ctx *ctx, int32_t n_obs, const d
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_predict_obstacles: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (!ctx->have_geom) return fail(ctx, -22, "jsim_loop_predict_obstacles: jsim_loop_set_geometry has not been called");
     if (n_obs < 0 || n_obs > JSIM_MAX_OBS || n_steps < 1 || n_steps > JSIM_MAX_PRED)
         return fail(ctx, -22, "jsim_loop_predict_obstacles: n_obs=%d (max %d), n_steps=%d (max %d)", n_obs, JSIM_MAX_OBS, n_steps, JSIM_MAX_PRED);
@@ -1940,6 +1988,7 @@ extern "C" int jsim_loop_pre_tick(jsim_ctx *ctx, int32_t B, const double *x0, co
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_pre_tick: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0 || frame_window < 0 || frame_window > 32 || margin < 0) return fail(ctx, -22, "jsim_loop_pre_tick: bad argument");
     if (B == 0) return 0;
     if (!x0 || !path_id || !traj_idx || !prev_path_len || !path_len || !col_flag || !status)
@@ -1966,6 +2015,7 @@ extern "C" int jsim_mpc_set_path_speed(jsim_ctx *ctx, const double *cv)
 {
     if (!ctx) return fail(nullptr, -22, "jsim_mpc_set_path_speed: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (ctx->d_pcv) { (void)hipFree(ctx->d_pcv); ctx->d_pcv = nullptr; }
     if (!cv) return 0; // back to the plain controller (no speed reference)
     if (ctx->n_points <= 0) return fail(ctx, -22, "jsim_mpc_set_path_speed: call jsim_mpc_set_paths first");
@@ -2006,6 +2056,7 @@ extern "C" int jsim_loop_obstacles(jsim_ctx *ctx, int32_t n_obs, double *state, 
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_obstacles: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (n_obs < 0 || n_obs > JSIM_MAX_OBS) return fail(ctx, -22, "jsim_loop_obstacles: n_obs=%d (max %d)", n_obs, JSIM_MAX_OBS);
     if (n_obs == 0) return 0;
     if (!state || !param) return fail(ctx, -22, "jsim_loop_obstacles: null device pointer");
@@ -2038,6 +2089,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
 {
     if (!ctx) return fail(nullptr, -22, "jsim_loop_run_scenario: null ctx");
     DeviceGuard dev_guard(ctx->device);
+    JSIM_GUARD_OK(ctx);
     if (B < 0 || n_ticks < 0 || frame_window < 0 || frame_window > 32 || margin < 0)
         return fail(ctx, -22, "jsim_loop_run_scenario: bad argument");
     if (B == 0 || n_ticks == 0) return 0;
@@ -2131,6 +2183,7 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     Q.col_flag = col_flag; Q.pre_status = pre_status;
     Q.speed_cutoff = speed_cutoff ? 1 : 0; Q.cut_io = glue_out;
     if (int rc_ = prepare_launch_order(ctx, B, s, K)) return rc_;
+    if (int rc_ = prepare_iter_totals(ctx, B, s, K)) return rc_;
     launch_reg(c.T, B, s, P, K, &Q);
     if (tick) hipLaunchKernelGGL(tick_add_kernel, dim3(1), dim3(1), 0, s, tick, n_ticks);
     HIP_TRY(ctx, hipGetLastError());

@@ -38,22 +38,9 @@ sys.path.insert(0, REPO)
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 matrix peak
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 
-# config -> (egos per GPU, horizon, route geometry, loop)
-CONFIGS = {
-    2: dict(batch=256, horizon=20, multi_lane=False, scenario=False,
-            name="BASELINE.json configs[1]: 256-ego batch, kinematic bicycle, horizon N=20, fp64"),
-    3: dict(batch=4096, horizon=30, multi_lane=False, scenario=True,
-            name="BASELINE.json configs[2]: 4096-ego batch, N=30, dynamic obstacles (four scripted vehicles: prediction, "
-                 "collision check and path cut-off inside every tick)"),
-    4: dict(batch=4096, horizon=20, multi_lane=False, scenario=False,
-            name="BASELINE.json configs[3]: 32768-ego batch over 8 GPUs = 4096 egos per GPU, N=20, fp64"),
-    5: dict(batch=1024, horizon=40, multi_lane=True, scenario=False,
-            name="BASELINE.json configs[4]: multi-lane geometry, 8192 egos over 8 GPUs = 1024 egos per GPU, N=40"),
-}
-OBSTACLE_SPECS = [dict(direction=1, turning=False, speed=25 / 3.6, offset=None),
-                  dict(direction=-1, turning=True, speed=20 / 3.6, offset=6.0),
-                  dict(direction=1, turning=True, speed=15 / 3.6, offset=12.0),
-                  dict(direction=-1, turning=False, speed=25 / 3.6, offset=3.0)]
+# The workloads (CONFIGS, OBSTACLE_SPECS, route tables, ego batches, loop objects) live in the package's workloads.py: ONE
+# definition shared with tests/test_gpu_bench_workloads.py, which checks these very egos and routes against the oracle.
+CONFIG_IDS = (2, 3, 4, 5)
 
 
 def algorithmic_bytes_per_step(T, w=8):
@@ -71,7 +58,7 @@ def kernel_name(T, scenario):
     if T in (13, 20, 30):
         return f"mpc_step_reg_kernel<{T}, {pre}>"
     if T == 40:
-        return f"mpc_step_reg2_kernel<{T}, {pre}>"
+        return f"mpc_step_reg4_kernel<{T}, {pre}>"
     return "mpc_step_kernel"
 
 
@@ -80,7 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2, help="BASELINE.json workload (see module docstring)")
+    ap.add_argument("--config", type=int, choices=CONFIG_IDS, default=2, help="BASELINE.json workload (see module docstring)")
     ap.add_argument("--batch", type=int, default=0, help="egos per GPU (0: the config's)")
     ap.add_argument("--horizon", type=int, default=0, help="horizon (0: the config's)")
     ap.add_argument("--mode", choices=("fused", "graph", "eager"), default="fused",
@@ -96,6 +83,8 @@ def parse_args(argv=None):
                     help="where an ego that reached its goal (or timed out) re-enters: its own random initial state, or the first point of "
                          "its route at standstill like the reference's scenarios start their vehicle")
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the config 4 / config 5 per-rank shares")
+    ap.add_argument("--no-respawn-start", action="store_true",
+                    help="skip the second, shorter run of the same workload under the other respawn rule (reported beside the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     return ap.parse_args(argv)
@@ -147,7 +136,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     pkg = importlib.import_module("av-simulation-at-intersections_amd")
-    S = pkg.synth
+    WL = pkg.workloads
+    CONFIGS, OBSTACLE_SPECS = WL.CONFIGS, WL.OBSTACLE_SPECS
     K, W = args.steps, args.warmup
 
     def sync_all():
@@ -160,53 +150,31 @@ def main():
     plan_info = {}   # row f4's own measurement: the planner launch that produced the workload's routes (rank 0 reports it)
 
     def route_table(multi_lane):
-        """the 12 routes of the reference's intersection() (configs 2-4) or of its two-lane scenario (config 5:
-        4 arms x 3 turns x 2 start lanes x 2 goal lanes = 48), planned here by the GPU planner (row f4); yaw unwrapped like MPC.__init__."""
         if multi_lane not in _route_cache:
-            if args.routes == "synthetic":
-                rs = S.make_route_table(multi_lane=multi_lane)
-            else:
-                PL = pkg.planner
-                rad, _ = PL.car_circles()
-                if multi_lane:
-                    qs = [PL.intersection_query(sp, tn, rad, sl, gl, number_of_lanes=2) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)
-                          for sl in (1, 2) for gl in (1, 2)]
-                else:
-                    qs = [PL.intersection_query(sp, tn, rad) for sp in (1, 2, 3, 4) for tn in (1, 2, 3)]
-                PL.plan_routes(qs[:1], device=dev_index)      # untimed: module load, first use of the entry point
-                t_p0 = time.perf_counter()
-                res = PL.plan_routes(qs, device=dev_index)
-                t_p1 = time.perf_counter()
-                if any(r.status != 0 for r in res):
-                    raise SystemExit(f"route planner: status {[r.status for r in res]}")
-                rs = [r.trajectory for r in res]
-                plan_info[multi_lane] = {"routes": len(qs), "wall_ms": (t_p1 - t_p0) * 1e3, "queries": qs,
-                                         "expanded": [int(r.n_expanded) for r in res], "points": int(sum(len(t) for t in rs))}
-            for r in rs:
-                S.smooth_yaw_inplace(r[:, 2])
+            rs, info = WL.route_table(multi_lane, source=args.routes, device_index=dev_index)
+            if info:
+                plan_info[multi_lane] = info
             _route_cache[multi_lane] = rs
         return _route_cache[multi_lane]
 
-    def run_workload(cfg_id, B, T, K, W, mode, tpl):
+    def iter_totals(eng, reset):
+        tot = np.zeros(eng.B, dtype=np.uint64)
+        pkg._cabi.check(eng.lib.jsim_mpc_iter_totals(eng._ctx, eng.B, tot.ctypes.data, 1 if reset else 0), eng._ctx, "jsim_mpc_iter_totals")
+        return tot
+
+    def run_workload(cfg_id, B, T, K, W, mode, tpl, respawn):
         """W untimed ticks, then EXACTLY K timed ticks bracketed by barrier + synchronize; returns the figures of this rank
         (elapsed = max over ranks)."""
         cfg = CONFIGS[cfg_id]
         routes = route_table(cfg["multi_lane"])
-        batch = S.make_ego_batch(routes, B, T, seed=1 + rank, truncate=False)
-        eng = pkg.BatchedMPC(routes, batch.path_id, dl=S.DL, T=T, speed=batch.speed, device=device, smooth=False)
-        eng.load_state(batch.target_ind, batch.oa, batch.od, batch.path_len)
-        x0 = torch.from_numpy(batch.x0).to(device)
-        if cfg["scenario"]:
-            sc = pkg.ScenarioLoop(eng, x0, OBSTACLE_SPECS, hist_cap=K + W + 64, max_age=400)
-            loop, tick, run = sc.loop, sc.tick, sc.run
+        batch = WL.ego_batch(routes, B, T, rank=rank)
+        eng, x0 = WL.make_engine(routes, batch, T, device)
+        sc, loop = WL.make_loop(cfg_id, eng, x0, hist_cap=K + W + 64, routes=routes, batch=batch, respawn=respawn)
+        if sc is not None:
+            tick, run = sc.tick, sc.run
             mode = "fused" if mode == "graph" else mode
         else:
-            loop = pkg.ClosedLoop(eng, x0, hist_cap=K + W + 8, max_age=400)
             tick, run = loop.tick, loop.run
-        if args.respawn == "start":   # State(x, y, yaw of the route's first point, v = 0): main/scenarios/mpc_intersection.py:78-79
-            first = np.array([[routes[p][0, 0], routes[p][0, 1], 0.0, routes[p][0, 2]] for p in batch.path_id])
-            loop.x0_spawn.copy_(torch.from_numpy(first).to(device))
-            loop.target_spawn.zero_()
 
         for _ in range(W):          # warm-up (untimed)
             tick()
@@ -229,6 +197,7 @@ def main():
             # untimed: first use of the entry point (the scenario entry sizes its per-launch obstacle buffers on first use, so
             # it is given a launch of the timed size)
             run(chunk if cfg["scenario"] else 1)
+            iter_totals(eng, reset=True)    # the counters of the timed launches start at zero (synchronises: outside the timed region)
         elif mode == "graph":
             loop.capture(chunk)     # (capture runs one extra untimed tick)
 
@@ -236,13 +205,14 @@ def main():
         # engine passes torch's current stream of this device to the C-ABI, and torch.cuda.Event records on that stream)
         evs, ncut = [], []
         pre_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K // chunk if mode == "fused" else 0)]
-        for ea, eb in pre_evs:        # (event objects are created lazily on first record: not inside the timed region)
+        gev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for ea, eb in pre_evs + [gev]:        # (event objects are created lazily on first record: not inside the timed region)
             ea.record(); eb.record()
         sync_all()
         t0 = time.perf_counter()
         if mode == "fused":         # closed loop on the device: `chunk` ticks per launch, egos never wait for each other
             for ea, eb in pre_evs:
-                if cfg["scenario"]:
+                if sc is not None:
                     sc.obst.reset()         # a 128-byte device-to-device copy on the launch stream
                     ncut.append((eng.path_len < eng.full_len).sum())     # of the previous launch's last tick (no sync here)
                 ea.record(); run(chunk); eb.record()
@@ -253,29 +223,51 @@ def main():
         else:
             for _ in range(K):
                 tick()
+        collective = None
         if world > 1:   # the only exchange of the job: gather every rank's recorded controls (RCCL all-gather)
             hist_local = loop.hist[:K].permute(1, 0, 2).contiguous()          # [B, K, 2]
+            gev[0].record()
             hist_all = gather(hist_local, B * world)
+            gev[1].record()
             assert hist_all.shape[0] == B * world
         sync_all()
         t1 = time.perf_counter()
-        eng_cut_last = (eng.path_len < eng.full_len).sum() if cfg["scenario"] else None
+        if world > 1:
+            # what the communicator itself says it is: backend and rank count come from the process group / the C-ABI's
+            # communicator, not from the command line
+            collective = {"what": "all-gather of the recorded controls [B, K, 2] f64, once per job",
+                          "backend": ("rccl via jsim_mpc_gather (ncclAllGather called by libjsim_mpc.so)" if cabi_gather else
+                                      f"torch.distributed {dist.get_backend()}" + (" (= RCCL on ROCm)" if dist.get_backend() == "nccl" else "")),
+                          "ranks": int(cabi_gather.world if cabi_gather else dist.get_world_size()),
+                          "bytes_per_rank": int(hist_local.numel() * hist_local.element_size()),
+                          "bytes_total": int(hist_all.numel() * hist_all.element_size()),
+                          # evidence in the data itself: rank blocks of the gathered tensor that arrived non-empty
+                          "rank_blocks_with_data": int((hist_all.reshape(world, -1).abs().sum(dim=1) > 0).sum().item()),
+                          "ms": float(gev[0].elapsed_time(gev[1]))}
+        eng_cut_last = (eng.path_len < eng.full_len).sum() if sc is not None else None
         elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cpu" if rehearsal else device)
         if world > 1:
             dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         elapsed = float(elapsed.item())
 
-        # ---- mean active-set iterations per step + (non-fused modes) the single-tick launch duration: KE more ticks,
-        # untimed for `value`, HIP events around the MPC kernel only
-        KE = min(K, 100)
-        sevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KE)]
-        n_iter_sum = torch.zeros((), dtype=torch.float64, device=device)
-        torch.cuda.synchronize(device)
-        if cfg["scenario"]:
-            for a, b in sevs:
-                a.record(); tick(); b.record()
-                n_iter_sum += eng.n_iter.sum()
+        straggler = None
+        if mode == "fused":
+            # iterations of the TIMED launches, per ego (jsim_mpc_iter_totals: every fused launch adds what each ego needed), and
+            # the dominant launch of the timed region IS the fused kernel: HIP events around each one
+            tot = iter_totals(eng, reset=False).astype(np.float64)
+            mean_iter = float(tot.sum()) / (K * B)
+            per_tick = tot / K
+            straggler = {"max_ego_iters_per_tick": round(float(per_tick.max()), 2),
+                         "slowest_over_mean": round(float(per_tick.max() / max(per_tick.mean(), 1e-30)), 2),
+                         "egos_above_3x_mean": int((per_tick > 3.0 * per_tick.mean()).sum())}
+            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            launches, ticks_per_launch = len(evs), chunk
         else:
+            # non-fused modes: KE more ticks, untimed for `value`, HIP events around the single-tick MPC launch only
+            KE = min(K, 100)
+            sevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(KE)]
+            n_iter_sum = torch.zeros((), dtype=torch.float64, device=device)
+            torch.cuda.synchronize(device)
             for a, b in sevs:
                 a.record(); eng.solve(loop.x0); b.record()
                 n_iter_sum += eng.n_iter.sum()
@@ -284,18 +276,15 @@ def main():
                     eng.di_ai.data_ptr(), eng.target_ind.data_ptr(), eng.path_id.data_ptr(), eng.path_len.data_ptr(),
                     loop.x0_spawn.data_ptr(), loop.target_spawn.data_ptr(), loop.age.data_ptr(), loop.max_age, None, None, 0,
                     loop.n_respawn.data_ptr(), eng._stream()), eng._ctx)
-        torch.cuda.synchronize(device)
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in sevs]))   # one single-tick launch
-        launches, ticks_per_launch = KE, 1
-        if mode == "fused":   # the dominant launch of the timed region IS the fused kernel: HIP events around each one
-            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-            launches, ticks_per_launch = len(evs), chunk
-        mean_iter = float(n_iter_sum.item()) / (KE * B)
+            torch.cuda.synchronize(device)
+            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in sevs]))   # one single-tick launch
+            launches, ticks_per_launch = KE, 1
+            mean_iter = float(n_iter_sum.item()) / (KE * B)
         res = dict(cfg_id=cfg_id, B=B, T=T, K=K, W=W, mode=mode, chunk=chunk, elapsed=elapsed, kern_ms=kern_ms,
-                   launches=launches, ticks_per_launch=ticks_per_launch, mean_iter=mean_iter,
+                   launches=launches, ticks_per_launch=ticks_per_launch, mean_iter=mean_iter, straggler=straggler,
                    n_fail=int((eng.status != 0).sum().item()), respawns=int(loop.n_respawn.item()),
-                   value=B * world * K / elapsed, routes=routes, batch=batch,
-                   cut=(float(torch.stack(ncut[1:] + [(eng_cut_last)]).double().mean().item()) if cfg["scenario"] else None))
+                   value=B * world * K / elapsed, routes=routes, batch=batch, collective=collective,
+                   cut=(float(torch.stack(ncut[1:] + [(eng_cut_last)]).double().mean().item()) if sc is not None else None))
         if cabi_gather:
             cabi_gather.close()
         eng.close()
@@ -304,16 +293,27 @@ def main():
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
     T = args.horizon or cfg["horizon"]
-    main_res = run_workload(args.config, B, T, K, W, args.mode, args.ticks_per_launch)
+    main_res = run_workload(args.config, B, T, K, W, args.mode, args.ticks_per_launch, args.respawn)
+    other = None
+    if args.mode == "fused" and not args.no_respawn_start:
+        # the same workload and kernels under the OTHER respawn rule, a shorter run of the same protocol: the default rule keeps
+        # re-injecting SURVEY 8d's perturbed states (a few egos get stuck beside their path and set the launch time: `straggler`),
+        # "start" lets a finished ego re-enter at its route's first point at standstill like the reference's scenarios
+        Ko = max(10, min(K, 100))
+        other_rule = "start" if args.respawn == "initial" else "initial"
+        r = run_workload(args.config, B, T, Ko, min(W, 10), "fused", 0, other_rule)
+        other = {"respawn": other_rule, "value": r["value"], "unit": "MPC steps/s", "steps": Ko, "ms_per_step": r["elapsed"] / Ko * 1e3,
+                 "mean_active_set_iters": round(r["mean_iter"], 2), "straggler": r["straggler"]}
     extra = {}
     if world > 1 and args.config == 2 and not args.no_extra and not (args.batch or args.horizon):
         for cid in (4, 5):   # the named multi-GPU configurations' per-rank shares, same job, same protocol, fewer ticks
             c = CONFIGS[cid]
             Ke = max(10, min(K, 100 if cid == 4 else 40))
-            r = run_workload(cid, c["batch"], c["horizon"], Ke, min(W, 5), "fused", 0)
+            r = run_workload(cid, c["batch"], c["horizon"], Ke, min(W, 5), "fused", 0, args.respawn)
             extra[f"config{cid}"] = {"workload": c["name"], "value": r["value"], "unit": "MPC steps/s", "egos_total": c["batch"] * world,
                                      "horizon": c["horizon"], "steps": Ke, "ms_per_step": r["elapsed"] / Ke * 1e3,
-                                     "mean_active_set_iters": round(r["mean_iter"], 2), "failed_egos_last_tick": r["n_fail"]}
+                                     "mean_active_set_iters": round(r["mean_iter"], 2), "straggler": r["straggler"],
+                                     "failed_egos_last_tick": r["n_fail"], "collective": r["collective"]}
 
     if rank == 0:
         r = main_res
@@ -323,8 +323,8 @@ def main():
         ach_tf = flops / (r["kern_ms"] * 1e-3) / 1e12
         ach_gbs = nbytes / (r["kern_ms"] * 1e-3) / 1e9
         traffic, traffic_source = None, "not measured in this run (PMC counters need their own rocprofv3 passes)"
-        pmc_path = os.path.join(REPO, "profiles", f"r02_config{args.config}_pmc_summary.json")
-        if r["mode"] == "fused" and (B, T) == (cfg["batch"], cfg["horizon"]) and os.path.exists(pmc_path):
+        pmc_path = latest_pmc_summary(args.config)
+        if r["mode"] == "fused" and (B, T) == (cfg["batch"], cfg["horizon"]) and pmc_path:
             # HBM bytes of one fused launch from the rocprofv3 PMC passes of this same command, collected in a SEPARATE run
             # (tools/collect_profile.sh): FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request), WRITE_SIZE as is,
             # both in KiB; scaled to this launch's tick count
@@ -332,7 +332,8 @@ def main():
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * (tpl / float(pmc.get("ticks_per_launch", 100)))
                 traffic_source = (f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc passes of this command "
-                                  f"({pmc.get('ticks_per_launch', 100)} ticks per launch), scaled to {tpl} ticks; stale if the kernel changed since")
+                                  f"({pmc.get('ticks_per_launch', 100)} ticks per launch, library at commit {pmc.get('commit', '?')}), "
+                                  f"scaled to {tpl} ticks; stale if the kernel changed since")
         waves = 4 if T == 40 else 1
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",
@@ -350,8 +351,10 @@ def main():
                                    "an ego that reaches its goal or times out re-enters at the first point of its route at standstill"),
                        "launch": {"fused": f"fused closed loop, {r['chunk']} ticks per launch", "graph": "hipGraph",
                                   "eager": "eager"}[r["mode"]], "parallelism": f"ego-shard x{world}",
-                       "mean_active_set_iters": round(r["mean_iter"], 2), "failed_egos_last_tick": r["n_fail"],
-                       "respawns": r["respawns"]},
+                       "mean_active_set_iters": round(r["mean_iter"], 2),
+                       "iters_source": ("the timed launches' own per-ego counters (jsim_mpc_iter_totals)" if r["mode"] == "fused" else
+                                        "extra single-tick launches after the timed region"),
+                       "straggler": r["straggler"], "failed_egos_last_tick": r["n_fail"], "respawns": r["respawns"]},
             "roofline": {"bound": "issue-latency", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name(T, cfg["scenario"]), "kernel_ms": r["kern_ms"],
@@ -362,6 +365,10 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes},
         }
+        if other:
+            out["other_respawn_rule"] = other
+        if r["collective"]:
+            out["collective"] = r["collective"]
         if cfg["scenario"]:
             out["config"]["obstacle_vehicles"] = len(OBSTACLE_SPECS)
             out["config"]["egos_cut_off_mean_at_launch_ends"] = r["cut"]
@@ -381,6 +388,13 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def latest_pmc_summary(config):
+    """profiles/rNN_config<config>_pmc_summary.json of the latest round that has one (None if there is none)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_config{config}_pmc_summary.json")))
+    return cands[-1] if cands else None
 
 
 def host_cpu_description():

@@ -216,6 +216,12 @@ int jsim_mpc_run_ticks(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, co
 int jsim_mpc_set_launch_order(jsim_ctx *ctx, int32_t enabled);
 int jsim_mpc_get_launch_order(jsim_ctx *ctx, int32_t B, int32_t *order, uint32_t *work);
 
+/* Per-ego running totals of active-set iterations of the fused launches (jsim_mpc_run_ticks, jsim_loop_run_scenario) since the
+ * last reset.  No reference counterpart (the reference never sees its solver's iterations, main/lib/mpc.py:196-199); this is
+ * the measurement hook bench.py takes mean iterations, algorithmic flops and the straggler statistic of the TIMED launches from.
+ * Copies totals [B] to a HOST array (may be NULL) and, with reset != 0, clears them; it synchronises. */
+int jsim_mpc_iter_totals(jsim_ctx *ctx, int32_t B, uint64_t *totals, int32_t reset);
+
 /* ---- the route planner: A* over motion primitives, a batch of route queries at once ----
  * Replaces MotionPrimitiveSearch(scenario, car_dimensions, mps, margin).run() -- main/lib/mp_search_ww_generic.py:136-257 with
  * main/lib/a_star.py:31-78 and main/lib/obstacles.py:157-176 -- which every scenario script calls once before its loop
