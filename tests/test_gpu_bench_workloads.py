@@ -52,6 +52,15 @@ def _compare(eng, ref, sl=slice(None), tol=1e-7):
     return err
 
 
+def _advance(pkg, eng, loop):
+    """The second half of ClosedLoop.tick(): plant step, history, goal test / respawn (jsim_loop_advance)."""
+    pkg._cabi.check(eng.lib.jsim_loop_advance(
+        eng._ctx, eng.B, loop.x0.data_ptr(), eng.oa.data_ptr(), eng.od.data_ptr(), eng.status.data_ptr(), eng.di_ai.data_ptr(),
+        eng.target_ind.data_ptr(), eng.path_id.data_ptr(), eng.path_len.data_ptr(), loop.x0_spawn.data_ptr(),
+        loop.target_spawn.data_ptr(), loop.age.data_ptr(), loop.max_age, loop.hist.data_ptr(), loop.tick_counter.data_ptr(),
+        loop.hist_cap, loop.n_respawn.data_ptr(), eng._stream()), eng._ctx, "jsim_loop_advance")
+
+
 def _inputs_fed_ticks(oracle, pkg, routes, eng, loop, batch, T, K, sl=slice(None), tol=1e-7):
     """K closed-loop ticks driven one by one; before every tick the device's inputs (state, remembered index, warm start, path
     length) are read back and given to the oracle, after the solve the outputs are compared.  Returns the worst |du|."""
@@ -61,10 +70,10 @@ def _inputs_fed_ticks(oracle, pkg, routes, eng, loop, batch, T, K, sl=slice(None
         tind = eng.target_ind.cpu().numpy()[sl].copy(); oa = eng.oa.cpu().numpy()[sl].copy(); od = eng.od.cpu().numpy()[sl].copy()
         plen = eng.path_len.cpu().numpy()[sl].copy()
         ref = _oracle_step(oracle, pkg, routes, T, x0, batch.path_id[sl], plen, batch.speed[sl], tind, oa, od)
-        loop.tick()
+        eng.solve(loop.x0)                       # loop.tick() = this solve + the advance below
         torch.cuda.synchronize()
-        # loop.tick() = solve + advance: the solve's outputs are still in the engine's buffers
         worst = max(worst, _compare(eng, ref, sl, tol))
+        _advance(pkg, eng, loop)
     return worst
 
 
@@ -178,11 +187,7 @@ def test_config3_scenario_loop_4096x30_glue_and_step_vs_oracles(pkg, oracle, pla
         eng.solve(loop.x0)
         torch.cuda.synchronize()
         worst = max(worst, _compare(eng, ref, tol=1e-6))
-        pkg._cabi.check(eng.lib.jsim_loop_advance(
-            eng._ctx, eng.B, loop.x0.data_ptr(), eng.oa.data_ptr(), eng.od.data_ptr(), eng.status.data_ptr(), eng.di_ai.data_ptr(),
-            eng.target_ind.data_ptr(), eng.path_id.data_ptr(), eng.path_len.data_ptr(), loop.x0_spawn.data_ptr(),
-            loop.target_spawn.data_ptr(), loop.age.data_ptr(), loop.max_age, loop.hist.data_ptr(), loop.tick_counter.data_ptr(),
-            loop.hist_cap, loop.n_respawn.data_ptr(), eng._stream()), eng._ctx, "jsim_loop_advance")
+        _advance(pkg, eng, loop)
         resp = loop.age == 0
         sc.pre.traj_idx.masked_fill_(resp, 0); sc.pre.prev_len.masked_fill_(resp, -1)
         sc.obst.get(step=True)
