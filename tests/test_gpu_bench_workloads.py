@@ -160,6 +160,7 @@ def test_config3_scenario_loop_4096x30_glue_and_step_vs_oracles(pkg, oracle, pla
     glue_slice = np.arange(0, B, B // 384)[:384]
     n_glue = n_col = n_cut = 0
     worst = 0.0
+    iters_by_tick = torch.zeros(B, dtype=torch.int64, device="cuda:0")
     for k in range(K):
         g = sc.obst.get(step=False)
         obst = g.cpu().numpy().copy()
@@ -187,6 +188,7 @@ def test_config3_scenario_loop_4096x30_glue_and_step_vs_oracles(pkg, oracle, pla
         eng.solve(loop.x0)
         torch.cuda.synchronize()
         worst = max(worst, _compare(eng, ref, tol=1e-6))
+        iters_by_tick += eng.n_iter.to(torch.int64)
         _advance(pkg, eng, loop)
         resp = loop.age == 0
         sc.pre.traj_idx.masked_fill_(resp, 0); sc.pre.prev_len.masked_fill_(resp, -1)
@@ -199,8 +201,15 @@ def test_config3_scenario_loop_4096x30_glue_and_step_vs_oracles(pkg, oracle, pla
     torch.cuda.synchronize()
     assert torch.equal(loop2.hist[:K], loop.hist[:K]) and torch.equal(loop2.x0, loop.x0)
     assert torch.equal(eng2.path_len, eng.path_len) and torch.equal(eng2.target_ind, eng.target_ind)
+    # the per-ego iteration totals bench.py reads from the timed launches == the per-tick counts added up
+    tot = np.zeros(B, dtype=np.uint64)
+    pkg._cabi.check(eng2.lib.jsim_mpc_iter_totals(eng2._ctx, B, tot.ctypes.data, 1), eng2._ctx, "jsim_mpc_iter_totals")
+    assert np.array_equal(tot.astype(np.int64), iters_by_tick.cpu().numpy())
+    pkg._cabi.check(eng2.lib.jsim_mpc_iter_totals(eng2._ctx, B, tot.ctypes.data, 0), eng2._ctx, "jsim_mpc_iter_totals")
+    assert not tot.any()                                       # reset
     print(f"config 3 at 4096 x 30, {K} ticks: glue of {len(glue_slice)} egos bit-exact every tick ({n_col} collision findings), "
-          f"{n_cut} truncated-path steps, MPC step of all egos vs oracle max|du|={worst:.2e}; fused launch == tick by tick")
+          f"{n_cut} truncated-path steps, MPC step of all egos vs oracle max|du|={worst:.2e}; fused launch == tick by tick; "
+          f"mean iterations per step {float(iters_by_tick.sum()) / (B * K):.2f}")
 
 
 def test_bench_line_fields():
