@@ -13,17 +13,19 @@ LIB = os.path.join(_HERE, "libjsim_mpc.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # S1-S3 follow numpy's operation order; fma() is explicit where wanted
                "-fno-fast-math",
-               # Round 1 blamed a wrong result of the two-wave kernel at T = 30 on spills into "free" AGPRs.  Round 2 could
-               # not support that: at the commit in question that instantiation compiles to byte-identical ISA with and
-               # without this option, and today's library passes every test either way.  The option
-               # stays because it is what all the parity evidence was collected with; it costs nothing measurable.
-               "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
                # MachineLICM hoists the materialisation of every 64-bit literal of the inlined sin / cos / tan polynomials
                # (and other loop-invariant address arithmetic) out of the K-tick loop, where the values then sit in
                # registers across the whole solve -- or, as happened, in scratch: ~20 doubles stored before the loop and
-               # reloaded in every tick.  Without it: no scratch at T = 13 / 20 / 30 (was 0 / 12 / 152-208 B), 40-60 fewer
-               # registers, 0 B (was 360 B) in the four-wave T = 40 kernel, speed within +-2 % on every configuration.
+               # reloaded in every tick.  Without it: no scratch at T = 20 / 30 (was 12 / 152-208 B), 84 B at T = 13 in its
+               # two-waves-per-SIMD build, 40-60 fewer registers, 0 B (was 360 B) in the four-wave T = 40 kernel, speed
+               # within +-2 % on every configuration.
                "-mllvm", "-disable-machine-licm"]
+# (Rounds 1-2 also passed -mllvm -amdgpu-spill-vgpr-to-agpr=0, first because a wrong result was blamed on AGPR spills, then
+# "because the evidence was collected with it".  Round 3 found the real cause of the wrong-row-id builds -- a live-range-split
+# copy placed in front of a join block's exec restore, DESIGN.md section 5 fact 7 -- which that option has no bearing on; every
+# build is now checked for that pattern (check_isa below) and the option is gone.)
+
+OBJ_DIR = os.path.join(os.path.dirname(_HERE), "build", "obj")   # hipcc's -save-temps output (the device .s the guard reads)
 
 
 def _hipcc() -> str:
@@ -41,13 +43,36 @@ def needs_build() -> bool:
     return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
 
 
+def check_isa(asm_path: str) -> None:
+    """The build-time guard of DESIGN.md section 5, fact 7: refuse a library in which a vector instruction sits in a join
+    block in front of that block's exec restore (tools/isa_exec_check.py explains the pattern and how it miscomputes)."""
+    import importlib.util
+    tool = os.path.join(os.path.dirname(_HERE), "tools", "isa_exec_check.py")
+    spec = importlib.util.spec_from_file_location("jsim_isa_exec_check", tool)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    findings = mod.check(asm_path)
+    if findings:
+        lines = [f"{k[:70]} block {b}: {len(ins)} vector instruction(s) in front of the exec restore at {asm_path}:{ln}"
+                 for k, b, ln, ins in findings]
+        raise RuntimeError("libjsim_mpc.so NOT installed -- the compiler placed vector code in front of a join block's exec "
+                           "restore (lanes outside the mask keep stale values; DESIGN.md section 5, fact 7):\n  " + "\n  ".join(lines))
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         extra = os.environ.get("JSIM_HIPCC_EXTRA", "").split()   # diagnostic builds (-DJSIM_STAMPS, -DJSIM_DEV_ONLY_T40, ...)
-        cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", INC, SRC, "-o", os.environ.get("JSIM_LIB_OUT", LIB)]
+        out = os.environ.get("JSIM_LIB_OUT", LIB)
+        obj_dir = OBJ_DIR if out == LIB else os.path.join(os.path.dirname(os.path.abspath(out)), "obj")
+        os.makedirs(obj_dir, exist_ok=True)
+        tmp_lib = os.path.join(obj_dir, "libjsim_mpc.so")
+        cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-save-temps=obj", "-I", INC, SRC, "-o", tmp_lib]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        check_isa(os.path.join(obj_dir, "jsim_mpc-hip-amdgcn-amd-amdhsa-gfx950.s"))
+        shutil.copyfile(tmp_lib, out)
+        os.chmod(out, 0o755)
     return LIB
 
 
