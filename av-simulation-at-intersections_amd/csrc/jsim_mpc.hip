@@ -1870,6 +1870,13 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     DeviceGuard dev_guard(device_id);
     JSIM_GUARD_OK(nullptr);
     const int R = n_routes, cap = node_cap, seg = n_pts - 1;
+    // sizes in 64 bits BEFORE anything is allocated: per route ~84 B per node slot (+ the hash table) and the output arrays
+    if (max_path > 4096 || n_pts > 4096) return fail(nullptr, -22, "jsim_plan_routes: max_path %d / points per primitive %d above 4096", max_path, n_pts);
+    {
+        const unsigned long long per_route = 84ull * (unsigned long long)cap * 3ull + 8ull * 3ull * (unsigned long long)max_path * (unsigned long long)seg;
+        if ((unsigned long long)R * per_route > (64ull << 30))
+            return fail(nullptr, -12, "jsim_plan_routes: %d routes x node_cap %d x max_path %d would need more than 64 GiB of device memory", R, cap, max_path);
+    }
     int hash_cap = 128;
     while (hash_cap < 2 * cap) hash_cap <<= 1;
     const size_t n_hp = (size_t)hp_off[n_obs_total], n_cc = (size_t)cc_off[n_prim];

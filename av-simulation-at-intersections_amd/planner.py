@@ -182,14 +182,24 @@ class MotionPrimitiveSearch:
 
     def __init__(self, scenario, car_dimensions, mps, margin: float,
                  wh_dist: float = 1.0, wh_theta: float = 2.7, wh_steering: float = 15.0, wh_obstacle: float = 0.0, wh_center: float = 0.0,
-                 wc_dist: float = 1.0, wc_steering: float = 5.0, wc_obstacle: float = 0.1, wc_center: float = 0.0, device: int = 0):
+                 wc_dist: float = 1.0, wc_steering: float = 5.0, wc_obstacle: float = 0.1, wc_center: float = 0.0, device: int = 0,
+                 max_path: int = 32, node_cap: int = 16384, retry_node_cap: int = 1 << 19):
+        # max_path: longest path in primitives the output arrays hold (status 6 beyond); node_cap / retry_node_cap: node table of
+        # the first / second attempt (status 4 beyond) -- the reference's dict and heap grow without bound, these do not
+        self.max_path, self.node_cap, self.retry_node_cap = int(max_path), int(node_cap), int(retry_node_cap)
         self._names = list(mps.keys())
         pts = [np.asarray(mps[n].points, dtype=np.float64) for n in self._names]
         if not pts or any(p.shape != pts[0].shape or p.ndim != 2 or p.shape[1] != 3 for p in pts):
             raise ValueError("motion primitives must be (n, 3) arrays of one common length")
         self._primitives = (np.stack(pts), np.array([float(mps[n].total_length) for n in self._names]))
         self._circles = (float(car_dimensions.radius), np.asarray(car_dimensions.circle_centers, dtype=np.float64).reshape(-1, 2))
-        (x1, y1), (x2, y2) = scenario.goal_area.xy1, scenario.goal_area.xy2
+        ga = scenario.goal_area
+        if not (hasattr(ga, "xy1") and hasattr(ga, "xy2")):
+            # the reference accepts any Obstacle with distance_to_point as goal area (main/lib/mp_search_ww_generic.py:101-103); every
+            # scenario builder it ships uses a BoxObstacle, and the kernel's goal test is the box test
+            raise ValueError(f"goal_area must be a box (.xy1 / .xy2), got {type(ga).__name__}: the GPU planner's goal test is the "
+                             "reference's BoxObstacle.distance_to_point(...) <= 0")
+        (x1, y1), (x2, y2) = ga.xy1, ga.xy2
         self._query = RouteQuery(start=tuple(float(v) for v in scenario.start), goal=tuple(float(v) for v in scenario.goal_point),
                                  goal_box=(float(x1), float(y1), float(x2), float(y2)), tol=float(scenario.allowed_goal_theta_difference),
                                  obstacles=[np.asarray(o.to_convex(margin=margin), dtype=np.float64) for o in scenario.obstacles])
@@ -202,12 +212,14 @@ class MotionPrimitiveSearch:
     def run(self, debug: bool = False):
         if debug:
             raise NotImplementedError("debug=True (the reference's expansion trace) is not offered by the GPU planner")
-        r = plan_routes([self._query], wh=self._wh, wc=self._wc, primitives=self._primitives, circles=self._circles, device=self._device)[0]
+        r = plan_routes([self._query], wh=self._wh, wc=self._wc, primitives=self._primitives, circles=self._circles, device=self._device,
+                        max_path=self.max_path, node_cap=self.node_cap, retry_node_cap=self.retry_node_cap)[0]
         self.last = r
         if r.status == 1:
             raise Exception("No solution found.")                    # main/lib/a_star.py:78
         if r.status != 0:
-            raise RuntimeError(f"route planner: status {r.status} (4: node table full, 5 / 6: path longer than the output arrays)")
+            raise RuntimeError(f"route planner: status {r.status} (4: node table full -- raise node_cap / retry_node_cap; 5 / 6: path "
+                               f"longer than max_path = {self.max_path} primitives)")
         path = [tuple(float(v) for v in n) for n in r.nodes]
         for a, b, k in zip(path[:-1], path[1:], r.prims):
             self._points_to_mp_names[a, b] = self._names[int(k)]

@@ -157,9 +157,13 @@ def test_two_rank_rehearsal_equals_unsharded(tmp_path):
     """shard -> solve (HIP) -> gather == unsharded, bit for bit, two processes on the one GPU of the box."""
     script = tmp_path / "w.py"
     script.write_text(_REHEARSAL_WORKER)
+    import socket
+    with socket.socket() as sk:                      # a free port, like bench.spawn_ranks (a fixed one collides with a lingering rendezvous)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, JSIM_REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29561", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("ok") == 2
@@ -178,6 +182,10 @@ def test_bench_gpus2_started_plainly_spawns_its_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 20 and j["config"]["egos_total"] == 512 and j["value"] > 0
     assert j["roofline"]["bound"] == "issue-latency" and "traffic_source" in j["roofline"]
+    # the collective block says what the communicator itself reports (here: gloo, two ranks, both blocks arrived with data)
+    c = j["collective"]
+    assert c["ranks"] == 2 and "gloo" in c["backend"] and c["rank_blocks_with_data"] == 2
+    assert c["bytes_per_rank"] == 256 * 20 * 2 * 8 and c["bytes_total"] == 2 * c["bytes_per_rank"] and c["ms"] >= 0.0
     assert set(j["extra"]) == {"config4", "config5"}
     assert j["extra"]["config4"]["egos_total"] == 8192 and j["extra"]["config5"]["horizon"] == 40
 
@@ -253,7 +261,7 @@ def test_cabi_gather_single_rank(pkg, routes):
     assert b"no communicator" in eng.lib.jsim_last_error(eng._ctx)
 
 
-@pytest.mark.parametrize("T,scenario", ((13, False), (20, True), (40, False)))
+@pytest.mark.parametrize("T,scenario", ((13, False), (20, True), (30, True), (40, False), (40, True)))
 def test_launch_order_changes_when_not_what(pkg, routes, T, scenario):
     """jsim_mpc_set_launch_order: with B >= 512 the fused launches hand workgroup b the ego that ranked b-th by the
     iterations of the previous launch.  (1) the history, final state and per-ego outputs are those of the identity order bit

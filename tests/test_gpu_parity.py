@@ -534,14 +534,15 @@ def test_fused_scenario_loop_equals_tick_by_tick(pkg, routes, T, max_age):
     assert int((a["pst"] != 0).sum()) == 0     # the glue never lost its footing (respawned egos restart their progress index)
 
 
-@pytest.mark.parametrize("T,K", ((40, 12), (20, 25)))
-def test_closed_loop_visited_states_against_oracle(pkg, oracle, routes, T, K):
+@pytest.mark.parametrize("T,K,B", ((40, 12, 64), (20, 25, 64), (40, 25, 256)))
+def test_closed_loop_visited_states_against_oracle(pkg, oracle, routes, T, K, B):
     """Parity on states a closed loop visits (the by-hand soak tests/soak_closed_loop.py in small): before every tick the
     oracle gets the kernel's inputs.  T = 40 with this seed reaches, at tick 8, an ego whose rows `v_1 <= speed` and
     `a_0 <= MAX_ACCEL` coincide (v_0 = speed - MAX_ACCEL * dt): equal entering keys up to rounding, non-unique multipliers --
-    with a 9-bit tie band kernel and oracle entered different rows of the pair; the band is 20 bits (jsim_key_trunc)."""
-    B = 64
-    batch = pkg.synth.make_ego_batch(routes, 256, T, seed=5)          # the soak's batch; its first 64 egos
+    with a 9-bit tie band kernel and oracle entered different rows of the pair; the band is 20 bits (jsim_key_trunc).
+    (40, 25, 256): the inputs-fed counterpart of test_fused_closed_loop_vs_oracle_closed_loop[40], whose two FREE-running loops are
+    only asked to stay within 1e-4 on 95 % of the egos -- here every ego, every tick, 1e-7, active sets identical."""
+    batch = pkg.synth.make_ego_batch(routes, 256, T, seed=5)          # the soak's batch; its first B egos
     sub = pkg.synth.EgoBatch(x0=batch.x0[:B].copy(), path_id=batch.path_id[:B].copy(), path_len=batch.path_len[:B].copy(),
                              target_ind=batch.target_ind[:B].copy(), speed=batch.speed[:B].copy(), oa=batch.oa[:B].copy(),
                              od=batch.od[:B].copy())
@@ -616,11 +617,60 @@ def test_scenario_loop_on_device_config1(pkg, routes):
     np.testing.assert_array_equal(sc.loop.x0.cpu().numpy(), x0.cpu().numpy())
 
 
+def test_config1_on_the_real_route_planned_and_driven_on_the_device(pkg):
+    """G4 on the real route: tests/golden/loop_real_T13.npz is the mpc_intersection loop run END TO END BY THE REFERENCE'S OWN CODE
+    (its planner's route for intersection(start_pos=1, turn_indicator=1), its MPC under the recording cvxpy stand-in, its two
+    MovingObstacleTIntersection, its collision check and plant: tests/golden/make_golden_loop_real.py; nothing under oracle/).
+    Here: the route is planned by jsim_plan_routes, then the device scenario loop is driven tick by tick and must reproduce
+    every recorded state, progress index, path length, collision flag, target_ind and control; then the same 91 ticks as ONE
+    fused scenario launch."""
+    g = load_golden("loop_real_T13.npz")
+    PL = pkg.planner
+    rad, _ = PL.car_circles()
+    res = PL.plan_routes([PL.intersection_query(1, 1, rad)], device=0)[0]
+    assert res.status == 0 and res.trajectory.shape == g["planned"].shape
+    np.testing.assert_allclose(res.trajectory, g["planned"], rtol=0, atol=1e-9)
+    full = res.trajectory.copy()
+    dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+    assert abs(dl - float(g["dl"])) <= 1e-12
+    specs = [dict(direction=int(d), offset=float(o), turning=bool(t), speed=float(s)) for d, o, t, s in g["obstacle_specs"]]
+    K = len(g["ticks"])
+
+    def fresh():
+        eng = pkg.BatchedMPC([full.copy()], [0], dl=dl, T=13)            # smooth=True: unwraps the yaw column like MPC.__init__
+        np.testing.assert_allclose(eng.paths[0][:, 2], g["trajectory_smoothed"][:, 2], rtol=0, atol=1e-9)
+        x0 = torch.tensor([[full[0, 0], full[0, 1], 0.0, eng.paths[0][0, 2]]], dtype=torch.float64, device=eng.device)
+        return eng, pkg.ScenarioLoop(eng, x0, specs, hist_cap=K, max_age=0)
+
+    eng, sc = fresh()
+    n_cut = 0
+    for k, row in enumerate(g["ticks"]):
+        x, y, yaw, v = row[:4]
+        np.testing.assert_allclose(sc.loop.x0[0].cpu().numpy(), [x, y, v, yaw], rtol=0, atol=1e-6)
+        sc.tick()
+        assert int(eng.path_len.item()) == int(row[7]) and int(eng.status.item()) == int(row[11]) == 0
+        assert int(sc.pre.col_flag.item()) == int(row[8])
+        if k < K - 1:     # the last recorded tick ends at the goal: the device loop respawns the ego there
+            assert int(eng.target_ind.item()) == int(row[10]) and int(sc.pre.traj_idx.item()) == int(row[6])
+            assert int(sc.loop.n_respawn.item()) == 0
+        n_cut += int(sc.pre.col_flag.item())
+    hist = sc.loop.hist[:K, 0].cpu().numpy()
+    d_ctrl = max(np.abs(hist[:, 0] - g["ticks"][:, 12]).max(), np.abs(hist[:, 1] - g["ticks"][:, 13]).max())
+    assert d_ctrl <= 1e-6, d_ctrl
+    assert n_cut == int(g["ticks"][:, 8].sum()) == 35 and int(sc.loop.n_respawn.item()) == 1
+    eng2, sc2 = fresh()
+    sc2.run(K)
+    torch.cuda.synchronize()
+    assert torch.equal(sc2.loop.hist[:K], sc.loop.hist[:K]) and torch.equal(sc2.loop.x0, sc.loop.x0)
+    print(f"config 1 on the reference's planned route: {K} ticks, {n_cut} with a cut-off, max control difference {d_ctrl:.2e}")
+
+
 @pytest.mark.parametrize("T", (30, 40))
-def test_two_wave_kernel_large_working_sets(pkg, oracle, routes, T):
+def test_large_working_sets_on_the_long_horizon_kernels(pkg, oracle, routes, T):
     """Tight limits (0.05 m/s^2, 0.4 deg/s steer rate) make most of the 8T rows bind: the working set outgrows one
-    wavefront's 64 lanes at T = 40, which is the only way to reach the second position slot of mpc_step_reg2_kernel
-    (and long Givens sweeps of drops) from a test.  Compared with the oracle under the same configuration."""
+    wavefront's 64 lanes at T = 40 -- the only way to reach working-set positions 64+ of the four-wave kernel
+    (mpc_step_reg4_kernel<40>) and the long Givens sweeps of drops in the one-wave T = 30 kernel from a test.  Compared with the
+    oracle under the same configuration."""
     B = 64
     cfg = pkg.MPCConfig.from_json()
     cfg.MAX_ACCEL, cfg.MAX_DECEL, cfg.MAX_DSTEER = 0.05, -0.05, 0.4
@@ -678,9 +728,10 @@ def test_speed_rows_in_the_working_set(pkg, oracle, routes, T):
 
 
 @pytest.mark.parametrize("T,B", ((30, 2048), (40, 1024)))
-def test_two_wave_kernel_at_scale_and_deterministic(pkg, oracle, routes, T, B):
-    """Two workgroups per CU, many rounds: every ego against the oracle (not just a KKT property), and two runs of the same
-    batch bit-identical -- cross-wave races would show up here as run-to-run differences."""
+def test_long_horizon_kernels_at_scale_and_deterministic(pkg, oracle, routes, T, B):
+    """T = 30 (one wave per ego, four egos per CU) and T = 40 (four waves per ego, two workgroups per CU), many rounds: every ego
+    against the oracle (not just a KKT property), and two runs of the same batch bit-identical -- cross-wave races would show up
+    here as run-to-run differences."""
     batch = pkg.synth.make_ego_batch(routes, B, T, seed=21, truncate=True, near_end_frac=0.2)
     outs = []
     for rep in range(2):

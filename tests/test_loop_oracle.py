@@ -74,6 +74,43 @@ def test_closed_loop_pre_tick_matches_reference_loop(LO, routes):
     assert n_cut >= 20 and bool(g["reached_goal"])
 
 
+def test_real_route_loop_of_the_reference_replayed_by_the_oracles(LO):
+    """tests/golden/loop_real_T13.npz: the mpc_intersection loop run by the REFERENCE's own code end to end -- its planner's route
+    for intersection(1, 1), its MPC (under the recording cvxpy stand-in), its obstacle vehicles, collision check and plant
+    (tests/golden/make_golden_loop_real.py; nothing under oracle/ took part).  Every tick: the oracle's loop glue reproduces
+    progress index, path length and collision flag bit for bit; the oracle's MPC step on the tick's inputs reproduces target_ind
+    and the applied controls to 1e-8; the oracle's plant step reproduces the next recorded state."""
+    g = load_golden("loop_real_T13.npz")
+    import oracle_py as O
+    full = g["trajectory_smoothed"]
+    assert full.shape == (720, 3) and abs(float(g["dl"]) - 0.083) < 1e-9
+    yaw = g["planned"][:, 2].copy()
+    assert np.array_equal(O.smooth_yaw(yaw), full[:, 2])                  # MPC.__init__ unwrapped the caller's yaw column in place
+    p = O.make_params(T=13, dl=float(g["dl"]))
+    assert LO.extra_cutoff_margin(float(g["dl"])) == int(g["margin"])
+    oa = od = None
+    n_cut, worst = 0, 0.0
+    T = g["ticks"]
+    for k, row in enumerate(T):
+        x, y, yaw_, v, idx_in, prev_len, idx_out, plen, hit, tind_in, tind_out, status, delta, accel, dev = row[:15]
+        obst = row[15:].reshape(-1, 6)
+        st, idx, path_len, col = LO.loop_pre_tick((x, y, yaw_, v), int(idx_in), None if prev_len < 0 else int(prev_len), full, obst, p.dl)
+        assert st == 0 and idx == int(idx_out) and path_len == int(plen) and (col is not None) == bool(hit), k
+        n_cut += bool(hit)
+        tr = full[:path_len]
+        r = O.mpc_step(p, (x, y, yaw_, v), tr[:, 0], tr[:, 1], tr[:, 2], int(tind_in), 30 / 3.6, oa=oa, od=od)
+        assert r["status"] == int(status) == 0 and r["target_ind"] == int(tind_out), k
+        worst = max(worst, abs(r["od"][0] - delta), abs(r["oa"][0] - accel))
+        assert abs(O.xref_deviation(tr[:, 0], tr[:, 1], tr[:, 2], int(tind_out), r["ox"][0], r["oy"][0]) - dev) <= 1e-9
+        oa, od = r["oa"], r["od"]
+        nxt = O.plant_step(p, np.array([x, y, v, yaw_]), accel, delta)      # [x, y, v, yaw] -> the next recorded State
+        want = T[k + 1][:4] if k + 1 < len(T) else g["final"]
+        np.testing.assert_allclose(nxt[[0, 1, 3, 2]], want, rtol=0, atol=1e-12)
+    assert worst <= 1e-8, worst
+    assert n_cut == 35 and len(T) == 91 and bool(g["reached_goal"])
+    assert O.is_goal(p, *g["final"][[0, 1, 3]], (full[-1, 0], full[-1, 1]), int(T[-1][10]), int(T[-1][7]))
+
+
 BIKE = (1.0, 0.45, 0.64)     # BicycleRealDimensions: wheelbase, bounding-box width, extra length (lib/car_dimensions.py:92-100)
 
 

@@ -193,6 +193,20 @@ def test_motion_primitive_search_dropin(pkg):
     with pytest.raises(Exception, match="No solution found"):
         PL.MotionPrimitiveSearch(walled, car, mps, margin=0.0).run()
 
+    # the surface is narrower than the reference's in two stated ways: box goal areas only, bounded tables (exposed on the class)
+    circ = NS(start=q.start, goal_point=q.goal, goal_area=NS(radius=2.0, xy_center=(0.0, 0.0)),
+              allowed_goal_theta_difference=q.tol, obstacles=[])
+    with pytest.raises(ValueError, match="goal_area must be a box"):
+        PL.MotionPrimitiveSearch(circ, car, mps, margin=rad)
+    short = PL.MotionPrimitiveSearch(scen, car, mps, margin=rad, max_path=3)
+    with pytest.raises(RuntimeError, match="max_path = 3"):
+        short.run()
+    small = PL.MotionPrimitiveSearch(scen, car, mps, margin=rad, node_cap=64, retry_node_cap=0)
+    with pytest.raises(RuntimeError, match="node table full"):
+        small.run()
+    with pytest.raises(pkg._cabi.JsimError, match="64 GiB"):       # sizes are bounded in 64 bits before anything is allocated
+        PL.plan_routes([q] * 4096, node_cap=1 << 24)
+
 
 def _stored_queries(pkg, g):
     """Route queries straight from the fixture's arrays (tests/golden/planner_envs.npz: scenario objects of the reference's
