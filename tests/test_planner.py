@@ -201,9 +201,10 @@ def test_motion_primitive_search_dropin(pkg):
     short = PL.MotionPrimitiveSearch(scen, car, mps, margin=rad, max_path=3)
     with pytest.raises(RuntimeError, match="max_path = 3"):
         short.run()
-    small = PL.MotionPrimitiveSearch(scen, car, mps, margin=rad, node_cap=64, retry_node_cap=0)
-    with pytest.raises(RuntimeError, match="node table full"):
-        small.run()
+    hard = _queries(pkg, g)[13]                                    # the golden route with 208 expansions: more than 64 nodes
+    r4 = PL.plan_routes([hard], node_cap=64, retry_node_cap=0)[0]
+    assert r4.status == 4                                          # node table full, no second attempt asked for
+    assert PL.plan_routes([hard], node_cap=64, retry_node_cap=1 << 14)[0].status == 0
     with pytest.raises(pkg._cabi.JsimError, match="64 GiB"):       # sizes are bounded in 64 bits before anything is allocated
         PL.plan_routes([q] * 4096, node_cap=1 << 24)
 
