@@ -1070,6 +1070,8 @@ static bool has_fused_glue(int T) { return has_reg_kernel(T); }
 static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
 {
     static const PreK none = {};
+    // more egos than SIMDs (256 CUs x 4): the T = 20 form built for two waves per SIMD (mpc_step_reg.inc, WPE)
+    static const int w2_min_b = [] { const char *e = getenv("JSIM_W2_MIN_B"); return e ? atoi(e) : 1025; }();
 #if defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
     if (T == 40) {
         if (Q) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
@@ -1078,27 +1080,29 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     return;
 #elif defined(JSIM_DEV_ONLY_T30) /* development builds: only the T = 30 one-wave kernel */
     if (T == 30) {
-        if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
+        if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else hipLaunchKernelGGL((mpc_step_reg_kernel<30, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
     }
     return;
-#elif defined(JSIM_DEV_ONLY_T20) /* development builds: only the T = 20 one-wave kernel */
+#elif defined(JSIM_DEV_ONLY_T20) /* development builds: only the T = 20 one-wave kernels */
     if (T == 20) {
-        if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else hipLaunchKernelGGL((mpc_step_reg_kernel<20, false>), dim3(B), dim3(64), 0, s, P, K, none);
+        if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (B >= w2_min_b) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none);
+        else hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
     }
     return;
 #else
     if (Q) { // the loop glue inside the launch
-        if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
         else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
         return;
     }
-    if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false>), dim3(B), dim3(64), 0, s, P, K, none);
-    else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false>), dim3(B), dim3(64), 0, s, P, K, none);
-    else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false>), dim3(B), dim3(64), 0, s, P, K, none);
+    if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 2>), dim3(B), dim3(64), 0, s, P, K, none);
+    else if (T == 20 && B >= w2_min_b) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none);
+    else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
+    else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
     else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
 #endif
 }

@@ -53,10 +53,12 @@ def algorithmic_flops_per_step(T, n_iter):
     return 16 * T ** 3 + 8 * T ** 3 / 3 + 40 * T ** 2 * n_iter + 32 * T ** 2 + 60 * T
 
 
-def kernel_name(T, scenario):
+def kernel_name(T, scenario, B):
+    """The kernel launch_reg (csrc/jsim_mpc.hip) dispatches: <T, PRE, waves per SIMD the register budget is set for>."""
     pre = "true" if scenario else "false"
     if T in (13, 20, 30):
-        return f"mpc_step_reg_kernel<{T}, {pre}>"
+        wpe = 2 if (not scenario and (T == 13 or (T == 20 and B > 1024))) else 1
+        return f"mpc_step_reg_kernel<{T}, {pre}, {wpe}>"
     if T == 40:
         return f"mpc_step_reg4_kernel<{T}, {pre}>"
     return "mpc_step_kernel"
@@ -335,6 +337,7 @@ def main():
                                   f"({pmc.get('ticks_per_launch', 100)} ticks per launch, library at commit {pmc.get('commit', '?')}), "
                                   f"scaled to {tpl} ticks; stale if the kernel changed since")
         waves = 4 if T == 40 else 1
+        per_simd = 2 if kernel_name(T, cfg["scenario"], B).endswith(", 2>") else 1
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",
             "value": r["value"], "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -357,10 +360,10 @@ def main():
                        "straggler": r["straggler"], "failed_egos_last_tick": r["n_fail"], "respawns": r["respawns"]},
             "roofline": {"bound": "issue-latency", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel_name(T, cfg["scenario"]), "kernel_ms": r["kern_ms"],
+                         "kernel": kernel_name(T, cfg["scenario"], B), "kernel_ms": r["kern_ms"],
                          "ticks_per_launch": tpl, "algorithmic_flops_per_launch": flops,
                          "note": ("priced against the fp64 vector = matrix peak; the kernel is bound by the issue latency of "
-                                  f"{waves} wave(s) per ego ({B} egos on 256 CUs / 1024 SIMDs), not by HBM (roofline_hbm) "
+                                  f"{waves} wave(s) per ego, {per_simd} wave(s) per SIMD ({B} egos on 256 CUs / 1024 SIMDs), not by HBM (roofline_hbm) "
                                   "and not by MFMA throughput (the MFMA pipe is < 1 % busy)")},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes},
