@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline $*"
+ARGS="${JSIM_PROFILE_ARGS:---steps 100 --warmup 10} --no-cpu-baseline --no-respawn-start $*"   # (one run of the workload: the dominant kernel's launches are then all of one kind)
 cd /tmp
 run() { # name, rocprof args...
     local name=$1; shift

@@ -29,7 +29,8 @@ name = max(dur, key=lambda k: max(dur[k]))   # the kernel of the timed region: t
 d = sorted(dur[name])
 fused = [x for x in d if x > 0.5 * d[-1]]          # the multi-tick launches
 single = [x for x in d if x <= 0.5 * d[-1]]
-out = {"kernel": name, "dispatches": len(d), "fused_launches": len(fused),
+out = {"commit": os.environ.get("JSIM_COMMIT", "?"),   # the library's source state (the GPU box has no .git: handed in by the caller)
+       "kernel": name, "dispatches": len(d), "fused_launches": len(fused),
        "fused_launch_ms_kernel_trace": sum(fused) / len(fused),
        "single_tick_launch_ms_kernel_trace": (sum(single) / len(single)) if single else None}
 for sub in ("fetch", "write", "sq1", "sq2"):
