@@ -135,6 +135,10 @@ __device__ __forceinline__ double uni(double v)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v)
+{
+    return ((long long)uni((int)(v >> 32)) << 32) | (long long)(unsigned)uni((int)v);
+}
 
 __device__ __forceinline__ double wsum(double v)
 {
