@@ -16,13 +16,13 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # MachineLICM hoists the materialisation of every 64-bit literal of the inlined sin / cos / tan polynomials
                # (and other loop-invariant address arithmetic) out of the K-tick loop, where the values then sit in
                # registers across the whole solve -- or, as happened, in scratch: ~20 doubles stored before the loop and
-               # reloaded in every tick.  Without it: no scratch at T = 20 / 30 (was 12 / 152-208 B), 84 B at T = 13 in its
-               # two-waves-per-SIMD build, 40-60 fewer registers, 0 B (was 360 B) in the four-wave T = 40 kernel, speed
-               # within +-2 % on every configuration.
+               # reloaded in every tick.  Without it: no scratch at T = 13 / 20 / 30 (was 0 / 12 / 152-208 B), 40-60 fewer registers, 0 B
+               # (was 360 B) in the four-wave T = 40 kernel, speed within +-2 % on every configuration.  (The one kernel with
+               # scratch today is T = 20's two-waves-per-SIMD form: 60 B, stored once per launch.)
                "-mllvm", "-disable-machine-licm"]
 # (Rounds 1-2 also passed -mllvm -amdgpu-spill-vgpr-to-agpr=0, first because a wrong result was blamed on AGPR spills, then
 # "because the evidence was collected with it".  Round 3 found the real cause of the wrong-row-id builds -- a live-range-split
-# copy placed in front of a join block's exec restore, DESIGN.md section 5 fact 7 -- which that option has no bearing on; every
+# copy placed in front of a join block's exec restore, DESIGN.md section 5 fact 6 -- which that option has no bearing on; every
 # build is now checked for that pattern (check_isa below) and the option is gone.)
 
 OBJ_DIR = os.path.join(os.path.dirname(_HERE), "build", "obj")   # hipcc's -save-temps output (the device .s the guard reads)
@@ -44,7 +44,7 @@ def needs_build() -> bool:
 
 
 def check_isa(asm_path: str) -> None:
-    """The build-time guard of DESIGN.md section 5, fact 7: refuse a library in which a vector instruction sits in a join
+    """The build-time guard of DESIGN.md section 5, fact 6: refuse a library in which a vector instruction sits in a join
     block in front of that block's exec restore (tools/isa_exec_check.py explains the pattern and how it miscomputes)."""
     import importlib.util
     tool = os.path.join(os.path.dirname(_HERE), "tools", "isa_exec_check.py")
@@ -56,7 +56,7 @@ def check_isa(asm_path: str) -> None:
         lines = [f"{k[:70]} block {b}: {len(ins)} vector instruction(s) in front of the exec restore at {asm_path}:{ln}"
                  for k, b, ln, ins in findings]
         raise RuntimeError("libjsim_mpc.so NOT installed -- the compiler placed vector code in front of a join block's exec "
-                           "restore (lanes outside the mask keep stale values; DESIGN.md section 5, fact 7):\n  " + "\n  ".join(lines))
+                           "restore (lanes outside the mask keep stale values; DESIGN.md section 5, fact 6):\n  " + "\n  ".join(lines))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -2,7 +2,7 @@
 """Build-time guard: vector instructions that sit in a JOIN block in front of its EXEC restore (gfx950, hipcc -S output).
 
 The pattern this finds is the cause of round 2's "multipliers attributed to the wrong rows" build of the T = 30 kernel
-(compiler fact 7):
+(compiler fact 6):
 
         s_and_saveexec_b64 s[4:5], s[6:7]      ; if (ok01) ...            divergent `if`
     ; %bb.705:                                 ;   then-block
