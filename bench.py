@@ -260,12 +260,7 @@ def main():
         if mode == "fused":
             # iterations of the TIMED launches, per ego (jsim_mpc_iter_totals: every fused launch adds what each ego needed), and
             # the dominant launch of the timed region IS the fused kernel: HIP events around each one
-            tot = iter_totals(eng, reset=False).astype(np.float64)
-            mean_iter = float(tot.sum()) / (K * B)
-            per_tick = tot / K
-            straggler = {"max_ego_iters_per_tick": round(float(per_tick.max()), 2),
-                         "slowest_over_mean": round(float(per_tick.max() / max(per_tick.mean(), 1e-30)), 2),
-                         "egos_above_3x_mean": int((per_tick > 3.0 * per_tick.mean()).sum())}
+            mean_iter, straggler = straggler_stats(iter_totals(eng, reset=False), K)
             kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
             launches, ticks_per_launch = len(evs), chunk
         else:
@@ -395,6 +390,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def straggler_stats(totals, K):
+    """(mean iterations per step, config.straggler) from the per-ego iteration totals of K timed ticks: a fused launch lasts as
+    long as its slowest ego, so the line says who that is -- its iterations per tick, their ratio to the mean, and how many egos
+    sit above three times the mean."""
+    import numpy as np
+    per_tick = np.asarray(totals, dtype=np.float64) / float(K)
+    mean = float(per_tick.mean()) if per_tick.size else 0.0
+    mx = float(per_tick.max()) if per_tick.size else 0.0
+    return mean, {"max_ego_iters_per_tick": round(mx, 2), "slowest_over_mean": round(mx / max(mean, 1e-30), 2),
+                  "egos_above_3x_mean": int((per_tick > 3.0 * mean).sum())}
 
 
 def latest_pmc_summary(config):

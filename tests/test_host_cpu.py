@@ -302,3 +302,30 @@ def test_plan_routes_argument_errors_without_gpu(pkg):
     assert call(r_off_=np.array([0, len(q.obstacles) + 1], dtype=np.int32)) == -22 and b"route_obs_off" in lib.jsim_last_error(None)
     bad = cc_off.copy(); bad[3] = bad[2] - 1
     assert call(cc_off_=bad) == -22 and b"cc_off" in lib.jsim_last_error(None)
+
+
+def test_bench_line_helpers():
+    """bench.py's pure pieces: the kernel launch_reg dispatches per (T, scenario, B), the straggler
+    statistic from per-ego iteration totals, the flop / byte formulas of SURVEY 8d, the newest committed PMC summary."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.kernel_name(40, False, 1024) == "mpc_step_reg4_kernel<40, false>" and bench.kernel_name(40, True, 64) == "mpc_step_reg4_kernel<40, true>"
+    assert bench.kernel_name(20, False, 256) == "mpc_step_reg_kernel<20, false, 1>" and bench.kernel_name(20, False, 1024) == "mpc_step_reg_kernel<20, false, 1>"
+    assert bench.kernel_name(20, False, 1025) == "mpc_step_reg_kernel<20, false, 2>" and bench.kernel_name(20, True, 4096) == "mpc_step_reg_kernel<20, true, 1>"
+    assert bench.kernel_name(13, False, 8) == "mpc_step_reg_kernel<13, false, 2>" and bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>"
+    assert bench.kernel_name(25, False, 8) == "mpc_step_kernel"
+    src = open(os.path.join(REPO, "av-simulation-at-intersections_amd", "csrc", "jsim_mpc.hip")).read()
+    assert "return e ? atoi(e) : 1025;" in src                      # the dispatch threshold kernel_name() mirrors
+    mean, s = bench.straggler_stats(np.array([100, 100, 100, 700], dtype=np.uint64), 10)
+    assert mean == 25.0 and s == {"max_ego_iters_per_tick": 70.0, "slowest_over_mean": 2.8, "egos_above_3x_mean": 0}
+    mean, s = bench.straggler_stats(np.array([10] * 99 + [1000], dtype=np.uint64), 10)
+    assert abs(mean - 1.99) < 1e-12 and s["egos_above_3x_mean"] == 1 and s["max_ego_iters_per_tick"] == 100.0
+    assert bench.algorithmic_bytes_per_step(20) == 2564 and bench.algorithmic_bytes_per_step(13) == 1717      # SURVEY 8d
+    assert abs(bench.algorithmic_flops_per_step(20, 20) - 0.4826e6) < 1e3                                      # 59 T^3-ish at n_iter = T
+    pm = bench.latest_pmc_summary(2)
+    assert pm and os.path.basename(pm) >= "r03_config2_pmc_summary.json"
+    d = json.load(open(pm))
+    assert "FETCH_SIZE" in d and "WRITE_SIZE" in d and d.get("commit", "?") != "?"
