@@ -39,6 +39,12 @@ def test_reference_step_live_vs_oracle(oracle, pkg, routes, T, n):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+        # leave no trace of the reference's packages: other tests import the repo's own `lib` shim under the same name
+        for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.") or k.split(".")[0] in ("bicycle", "envs")]:
+            if getattr(sys.modules[k], "__file__", "") and "/root/reference" in (sys.modules[k].__file__ or ""):
+                del sys.modules[k]
+        while REF_MAIN in sys.path:
+            sys.path.remove(REF_MAIN)
     mx = lambda k: max(f.get(k, 0.0) for f in figs)
     assert all(f["status_equal"] and f["target_equal"] and f["xref_equal"] for f in figs)
     assert mx("dH") <= 1e-12 and mx("dG") <= 1e-12 and mx("dh") <= 1e-12 and mx("dg") <= 1e-11
