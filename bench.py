@@ -324,7 +324,7 @@ def main():
         ach_tf = flops / (r["kern_ms"] * 1e-3) / 1e12
         ach_gbs = nbytes / (r["kern_ms"] * 1e-3) / 1e9
         traffic, traffic_source = None, "not measured in this run (PMC counters need their own rocprofv3 passes)"
-        pmc_path = latest_pmc_summary(args.config)
+        pmc_path = latest_pmc_summary(args.config, tpl)
         if r["mode"] == "fused" and (B, T) == (cfg["batch"], cfg["horizon"]) and pmc_path:
             # HBM bytes of one fused launch from the rocprofv3 PMC passes of this same command, collected in a SEPARATE run
             # (tools/collect_profile.sh): FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request), WRITE_SIZE as is,
@@ -404,11 +404,24 @@ def straggler_stats(totals, K):
                   "egos_above_3x_mean": int((per_tick > 3.0 * mean).sum())}
 
 
-def latest_pmc_summary(config):
-    """profiles/rNN_config<config>_pmc_summary.json of the latest round that has one (None if there is none)."""
+def latest_pmc_summary(config, ticks_per_launch=None):
+    """profiles/rNN_config<config>*_pmc_summary.json of the latest round that has one (None if there is none); among that round's
+    files the one collected at this launch length wins (the driver's `--steps 20` invocation has its own collection)."""
     import glob
-    cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_config{config}_pmc_summary.json")))
-    return cands[-1] if cands else None
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_config{config}*_pmc_summary.json")))
+    if not cands:
+        return None
+    rnd = os.path.basename(cands[-1])[:3]
+    cands = [c for c in cands if os.path.basename(c).startswith(rnd)]
+    if ticks_per_launch is not None:
+        for c in cands:
+            try:
+                if int(json.load(open(c)).get("ticks_per_launch", -1)) == int(ticks_per_launch):
+                    return c
+            except Exception:
+                pass
+    plain = [c for c in cands if os.path.basename(c) == f"{rnd}_config{config}_pmc_summary.json"]
+    return plain[0] if plain else cands[-1]
 
 
 def host_cpu_description():

@@ -326,6 +326,9 @@ def test_bench_line_helpers():
     assert bench.algorithmic_bytes_per_step(20) == 2564 and bench.algorithmic_bytes_per_step(13) == 1717
     assert abs(bench.algorithmic_flops_per_step(20, 20) - 0.4826e6) < 1e3                                      # 59 T^3-ish at n_iter = T
     pm = bench.latest_pmc_summary(2)
-    assert pm and os.path.basename(pm) >= "r03_config2_pmc_summary.json"
+    assert pm and os.path.basename(pm) >= "r03_config2_pmc_summary.json" and "driver" not in pm
+    pm20 = bench.latest_pmc_summary(2, 20)                         # the driver's --steps 20 invocation has its own collection
+    assert "driver_invocation" in pm20 and json.load(open(pm20))["ticks_per_launch"] == 20
+    assert bench.latest_pmc_summary(2, 100) == pm and bench.latest_pmc_summary(2, 37) == pm
     d = json.load(open(pm))
     assert "FETCH_SIZE" in d and "WRITE_SIZE" in d and d.get("commit", "?") != "?"
