@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -1887,6 +1888,42 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     }
     int hash_cap = 128;
     while (hash_cap < 2 * cap) hash_cap <<= 1;
+    // a circle around every obstacle (the kernel's exact pruning of the collision test): vertices = the pairwise intersections of its
+    // half-plane boundaries that satisfy all the others; bounded iff the largest angular gap between consecutive normals is below pi
+    std::vector<double> obc((size_t)(n_obs_total > 0 ? n_obs_total : 1) * 3, 0.0);
+    for (int o = 0; o < n_obs_total; ++o) {
+        const double *q = hp + (size_t)hp_off[o] * 3;
+        const int n = hp_off[o + 1] - hp_off[o];
+        double *c = &obc[(size_t)o * 3];
+        c[0] = 0.0; c[1] = 0.0; c[2] = INFINITY;
+        if (n < 3 || n > 64) continue;
+        double ang[64];
+        for (int i = 0; i < n; ++i) ang[i] = atan2(q[3 * i + 1], q[3 * i]);
+        std::sort(ang, ang + n);
+        double gap = ang[0] + 2.0 * M_PI - ang[n - 1];
+        for (int i = 1; i < n; ++i) gap = std::max(gap, ang[i] - ang[i - 1]);
+        if (!(gap < M_PI - 1e-9)) continue;                       // unbounded (or degenerate): no circle, never pruned
+        double sx = 0.0, sy = 0.0, vx[64 * 2], vy[64 * 2];
+        int nv = 0;
+        for (int i = 0; i < n && nv < 128; ++i)
+            for (int j = i + 1; j < n && nv < 128; ++j) {
+                const double a1 = q[3 * i], b1 = q[3 * i + 1], c1 = q[3 * i + 2], a2 = q[3 * j], b2 = q[3 * j + 1], c2 = q[3 * j + 2];
+                const double det = a1 * b2 - a2 * b1;
+                if (fabs(det) <= 1e-12 * (fabs(a1) + fabs(b1)) * (fabs(a2) + fabs(b2))) continue;
+                const double px = (b1 * c2 - b2 * c1) / det, py = (a2 * c1 - a1 * c2) / det;
+                bool in = std::isfinite(px) && std::isfinite(py);
+                for (int k = 0; k < n && in; ++k) {
+                    const double v = q[3 * k] * px + q[3 * k + 1] * py + q[3 * k + 2];
+                    in = v <= 1e-9 * (1.0 + fabs(q[3 * k + 2]) + (fabs(q[3 * k]) + fabs(q[3 * k + 1])) * (fabs(px) + fabs(py)));
+                }
+                if (in) { vx[nv] = px; vy[nv] = py; sx += px; sy += py; ++nv; }
+            }
+        if (nv < 3) continue;                                     // (an empty or degenerate set: left to the exact test)
+        const double mx = sx / nv, my = sy / nv;
+        double rr = 0.0;
+        for (int i = 0; i < nv; ++i) rr = std::max(rr, hypot(vx[i] - mx, vy[i] - my));
+        c[0] = mx; c[1] = my; c[2] = rr * (1.0 + 1e-9) + 1e-9;
+    }
     const size_t n_hp = (size_t)hp_off[n_obs_total], n_cc = (size_t)cc_off[n_prim];
     std::vector<void *> owned;
     auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes ? bytes : 8) != hipSuccess) return nullptr; owned.push_back(q); return q; };
@@ -1905,6 +1942,7 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     P.goal_box = (const double *)put(goal_box, sizeof(double) * 4 * R); P.tol = (const double *)put(tol, sizeof(double) * R);
     P.hp = (const double *)put(hp, sizeof(double) * 3 * n_hp); P.hp_off = (const int *)put(hp_off, sizeof(int) * (n_obs_total + 1));
     P.route_obs_off = (const int *)put(route_obs_off, sizeof(int) * (R + 1));
+    P.obc = (const double *)put(obc.data(), sizeof(double) * obc.size());
     P.mp_pts = (const double *)put(mp_pts, sizeof(double) * 3 * (size_t)n_prim * n_pts); P.mp_len = (const double *)put(mp_len, sizeof(double) * n_prim);
     P.cc_pts = (const double *)put(cc_pts, sizeof(double) * 2 * n_cc); P.cc_off = (const int *)put(cc_off, sizeof(int) * (n_prim + 1));
     P.nx = (double *)dalloc(sizeof(double) * (size_t)R * cap); P.ny = (double *)dalloc(sizeof(double) * (size_t)R * cap);
@@ -1917,7 +1955,7 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
     P.prims = (int *)dalloc(sizeof(int) * (size_t)R * max_path); P.cost = (double *)dalloc(sizeof(double) * R);
     P.nodes = (double *)dalloc(sizeof(double) * (size_t)R * (max_path + 1) * 3);
     P.traj = (double *)dalloc(sizeof(double) * (size_t)R * max_path * seg * 3);
-    if (!P.start || !P.goal || !P.goal_box || !P.tol || !P.hp || !P.hp_off || !P.route_obs_off || !P.mp_pts || !P.mp_len || !P.cc_pts ||
+    if (!P.start || !P.goal || !P.goal_box || !P.tol || !P.hp || !P.hp_off || !P.route_obs_off || !P.obc || !P.mp_pts || !P.mp_len || !P.cc_pts ||
         !P.cc_off || !P.nx || !P.ny || !P.nth || !P.ng || !P.nparent || !P.nprim || !P.htab || !P.ov_gh || !P.ov_g || !P.ov_id || !P.status || !P.n_prims || !P.n_expanded || !P.prims ||
         !P.cost || !P.nodes || !P.traj) {
         cleanup();
