@@ -74,6 +74,35 @@ _Z4kernv:                               ; @_Z4kernv
 	s_or_b64 exec, exec, s[6:7]
 	v_mov_b32_e32 v3, 0
 	s_or_b64 exec, exec, s[4:5]
+	s_and_saveexec_b64 s[6:7], s[4:5]
+	s_cbranch_execz .LBB13_389
+.LBB13_382:                             ; a region with uniform control flow inside ...
+	s_cmpk_lt_u32 s45, 0x1000
+	s_cbranch_scc1 .LBB13_384
+; %bb.383:
+	global_store_dword v13, v12, s[14:15]
+.LBB13_384:
+	s_andn2_b64 vcc, exec, s[14:15]
+	s_cbranch_vccnz .LBB13_386
+; %bb.385:
+	ds_write_b32 v2, v12
+.LBB13_386:                             ; ... whose last block does real work and ends with the merged restore
+	v_or_b32_e32 v7, s15, v7
+	v_mov_b32_e32 v18, s40
+	s_or_b64 exec, exec, s[6:7]
+.LBB13_389:
+	s_endpgm
+"""
+BAD_B = """
+_Z5kern2v:                              ; @_Z5kern2v
+; %bb.0:
+	s_and_saveexec_b64 s[4:5], s[6:7]
+	s_cbranch_execz .LBB1_2
+; %bb.1:
+	v_add_f64 v[0:1], v[0:1], v[2:3]
+.LBB1_2:                                ; the skip target = the join block, with a copy in front of its restore
+	v_accvgpr_write_b32 a46, v33
+	s_or_b64 exec, exec, s[4:5]
 	s_endpgm
 """
 
@@ -85,6 +114,10 @@ def test_guard_finds_the_round2_pattern_and_only_that(tmp_path):
     f = T.check(str(bad))
     assert len(f) == 1 and f[0][1] == "%bb.706" and [c for _, c in f[0][3]] == ["v_accvgpr_write_b32 a46, v33", "v_accvgpr_write_b32 a10, v229"]
     assert T.check(str(good)) == []
+    badb = tmp_path / "bad_b.s"
+    badb.write_text(BAD_B)
+    fb = T.check(str(badb))
+    assert len(fb) == 1 and fb[0][1] == ".LBB1_2"
 
 
 def test_shipped_library_has_no_finding(pkg):

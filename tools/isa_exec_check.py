@@ -53,26 +53,36 @@ def kernels(path):
     return out
 
 
+COPY = re.compile(r"^(v_mov_b32|v_mov_b64|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32)")
+
+
 def check_kernel(ins):
-    """A block is a REGION BODY if it directly follows an exec-narrowing instruction (+ its skip branch), or is the target of the
-    `s_cbranch_execnz` that follows one: its code runs under the narrowed mask by construction, and block placement may have
-    merged the region's exec restore into its tail.  Any OTHER block that has vector instructions in front of its first exec
-    restore is a join block with code on the wrong side of the restore."""
-    body_labels = set()
+    """Which blocks hold vector instructions in front of their first exec restore, and which of those are the bug.
+
+    Legitimate: the restore merged into the TAIL of a region body -- a block that directly follows the exec-narrowing instruction
+    (+ its skip branch), the target of the `s_cbranch_execnz` that follows one, or a later block of a region that has uniform
+    control flow inside (labelled, reached by scalar branches) and ends with real work.
+    The bug (a JOIN block with a live-range-split / spill copy on the wrong side of its restore) shows as one of
+      (a) an unlabelled block entered by pure fall-through (no branch in front of its `; %bb.N:` marker): it is a separate block only
+          because it has a second predecessor whose branch was elided -- the `s_cbranch_execz` of a short then-block;
+      (b) a labelled block that is the target of an `s_cbranch_execz`: the skip target IS the join block;
+      (c) any other non-body block in which everything in front of the restore is a pure register copy."""
+    body_labels, skip_labels = set(), set()
     for i, (ln, c) in enumerate(ins):
         if c.startswith("s_cbranch_execnz") and i > 0 and NARROW.match(ins[i - 1][1]):
             body_labels.add(c.split()[1])
+        if c.startswith("s_cbranch_execz"):
+            skip_labels.add(c.split()[1])
     findings = []
-    i, n = 0, len(ins)
-    while i < n:
-        ln, c = ins[i]
+    n = len(ins)
+    for i, (ln, c) in enumerate(ins):
         if not c.startswith("#"):
-            i += 1
             continue
         name = c[1:]
-        # what precedes the block boundary
         j = i - 1
-        if j >= 0 and ins[j][1].startswith("s_cbranch_exec"):
+        prev = ins[j][1] if j >= 0 else ""
+        after_branch = prev.startswith("s_cbranch") or prev.startswith("s_branch")
+        if j >= 0 and prev.startswith("s_cbranch_exec"):
             j -= 1
         is_body = (j >= 0 and bool(NARROW.match(ins[j][1]))) or name in body_labels
         pending, k = [], i + 1
@@ -81,14 +91,22 @@ def check_kernel(ins):
             op = code.split()[0]
             if RESTORE.match(code):
                 if pending and not is_body:
-                    findings.append((name, ins[k][0], pending))
+                    labelled = name.startswith(".LBB")
+                    kind = None
+                    if not labelled and not after_branch and not (i > 0 and NARROW.match(prev)):
+                        kind = "a"
+                    elif labelled and name in skip_labels:
+                        kind = "b"
+                    elif all(COPY.match(cc.split()[0]) for _, cc in pending):
+                        kind = "c"
+                    if kind:
+                        findings.append((name, ins[k][0], pending))
                 break                              # only what precedes the FIRST restore of the block is in question
             if NARROW.match(code) or op.startswith("s_cbranch") or op == "s_branch":
                 break
             if VEC.match(op) and not HARMLESS.match(op):
                 pending.append((ins[k][0], code))
             k += 1
-        i += 1
     return findings
 
 
