@@ -1077,7 +1077,10 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     static const PreK none = {};
     // more egos than SIMDs (256 CUs x 4): the T = 20 form built for two waves per SIMD (mpc_step_reg.inc, WPE)
     static const int w2_min_b = [] { const char *e = getenv("JSIM_W2_MIN_B"); return e ? atoi(e) : 1025; }();
-#if defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
+#if defined(JSIM_DEV_NO_REG) /* development builds of the planner / glue: no register kernel is instantiated */
+    (void)T; (void)B; (void)s; (void)P; (void)K; (void)Q; (void)none; (void)w2_min_b;
+    return;
+#elif defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
     if (T == 40) {
         if (Q) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
         else hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
@@ -1971,6 +1974,18 @@ extern "C" int jsim_plan_routes(int device_id, int32_t n_routes, const double *s
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
+#ifdef JPL_STAMPS
+    {
+        static long long clk[64][32];
+        (void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(jpl_clk), sizeof(clk));
+        for (int r_ = 0; r_ < R && r_ < 64; ++r_)
+            if (clk[r_][7] > 1000) {
+                fprintf(stderr, "jpl route %d: %lld expansions, %lld nodes, %lld open at the end; per expansion:", r_, clk[r_][7], clk[r_][13], clk[r_][14]);
+                for (int k = 0; k < 32; ++k) if (k != 7 && k != 13 && k != 14) fprintf(stderr, " [%d] %.2f", k, (double)clk[r_][k] / clk[r_][7]);
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
     if (e == hipSuccess) e = hipMemcpy(status, P.status, sizeof(int) * R, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(cost, P.cost, sizeof(double) * R, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(n_prims, P.n_prims, sizeof(int) * R, hipMemcpyDeviceToHost);

@@ -158,7 +158,7 @@ class PlannedRoute:
 
 
 def plan_routes(queries: Sequence[RouteQuery], L: float = 2.86, wh=WH_DEFAULT, wc=WC_DEFAULT, max_path: int = 32,
-                device: int = 0, primitives=None, node_cap: int = 16384, retry_node_cap: int = 1 << 19, circles=None) -> List[PlannedRoute]:
+                device: int = 0, primitives=None, node_cap: int = 1 << 17, retry_node_cap: int = 1 << 21, circles=None) -> List[PlannedRoute]:
     """All queries in ONE launch (one wavefront per route).  Routes whose search outgrows `node_cap` nodes (status 4) are planned
     again, together, with `retry_node_cap` (0: no second attempt).  primitives = (points [P, n, 3], total_length [P]) and
     circles = (radius, centres [k, 2]) replace the regenerated bicycle-model set / BicycleModelDimensions' circles."""
@@ -183,7 +183,7 @@ class MotionPrimitiveSearch:
     def __init__(self, scenario, car_dimensions, mps, margin: float,
                  wh_dist: float = 1.0, wh_theta: float = 2.7, wh_steering: float = 15.0, wh_obstacle: float = 0.0, wh_center: float = 0.0,
                  wc_dist: float = 1.0, wc_steering: float = 5.0, wc_obstacle: float = 0.1, wc_center: float = 0.0, device: int = 0,
-                 max_path: int = 32, node_cap: int = 16384, retry_node_cap: int = 1 << 19):
+                 max_path: int = 32, node_cap: int = 1 << 17, retry_node_cap: int = 1 << 21):
         # max_path: longest path in primitives the output arrays hold (status 6 beyond); node_cap / retry_node_cap: node table of
         # the first / second attempt (status 4 beyond) -- the reference's dict and heap grow without bound, these do not
         self.max_path, self.node_cap, self.retry_node_cap = int(max_path), int(node_cap), int(retry_node_cap)

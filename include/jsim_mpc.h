@@ -235,8 +235,8 @@ int jsim_mpc_iter_totals(jsim_ctx *ctx, int32_t B, uint64_t *totals, int32_t res
  *   primitive in its own frame (_create_collision_points, :118-136).  wh [5] = (dist, theta, steering, obstacle, center) of the
  *   heuristic, wc [4] = (dist, steering, obstacle, center) of the edge cost (:29-33; the scenarios use the defaults
  *   (1, 2.7, 15, 0, 0) / (1, 5, 0.1, 0)).
- *   node_cap: search workspace per route in nodes (16384 covers the reference's 18 standard routes a hundred times over; a
- *   route that reports status 4 wants more -- the two-lane scenario's lane changes need up to ~250k).
+ *   node_cap: search workspace per route in nodes, ~100 B each (16384 covers the reference's 18 standard routes a hundred
+ *   times over; the longest lane change of the two-lane scenario makes 85k; a route that reports status 4 wants more).
  *   Out: status [R] (0 found; 1 no solution -- the reference raises Exception("No solution found."); 4 search workspace
  *   exhausted; 5 obstacle / primitive set too large for the kernel; 6 path longer than max_path), cost [R], n_prims [R],
  *   prims [R][max_path] (primitive index per segment), nodes [R][max_path + 1][3], traj [R][max_path * (n_pts - 1)][3] (the first
