@@ -10,6 +10,10 @@ from typing import List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_CONFIG_PATH = os.path.join(_HERE, "mpc_config.json")
+# Horizons with a register-resident kernel in libjsim_mpc.so (csrc/jsim_mpc.hip: JSIM_ONE_WAVE_HORIZONS / JSIM_FOUR_WAVE_HORIZONS; a
+# CPU test compares the lists).  Any other T <= 48 runs on the LDS kernel: same results, 4-6 x slower.
+ONE_WAVE_HORIZONS = (13, 15, 16, 20, 25, 30)
+FOUR_WAVE_HORIZONS = (32, 40)
 
 
 def deg2rad(x: float) -> float:

@@ -112,7 +112,15 @@ __device__ __forceinline__ void jsim_apply_ego_cfg(KPT &P, const double *pe, int
 // ---------------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
 // ---------------------------------------------------------------------------------------------------
-#define LDS_SYNC() __syncthreads() /* single-wave workgroup: orders LDS traffic, the barrier itself is free */
+// Between two phases of a ONE-wave workgroup that hand data from lane to lane through LDS.  The hardware needs nothing -- a wave's LDS
+// operations are carried out in program order -- and the compiler only has to keep that order: a wavefront-scope fence.
+// __syncthreads() (rounds 1-2) drops its s_barrier in a 64-thread workgroup but keeps `s_waitcnt lgkmcnt(0)`: every hand-over waited
+// for its writes to COMPLETE before the reads were even issued.  (-DJSIM_LDS_SYNC_BARRIER: the old form, for A/B runs.)
+#ifdef JSIM_LDS_SYNC_BARRIER
+#define LDS_SYNC() __syncthreads()
+#else
+#define LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 #ifdef JSIM_STAMPS
 #define STAMP(i) do { if (P.dbg_clk && lane == 0) P.dbg_clk[(size_t)ego * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1067,9 +1075,31 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 #include "reg_common.inc"
 #include "mpc_step_reg4.inc"
 
-// horizons with a register-resident kernel: 13 / 20 (3T+1 <= 64 lanes: one wavefront per ego, every row stored), 30 (one wavefront,
-// virtual speed rows), 40 (four wavefronts, two lanes per row)
-static bool has_reg_kernel(int T) { return T == 13 || T == 20 || T == 30 || T == 40; }
+// Horizons with a register-resident kernel.  One wavefront per ego: every row stored for 13 <= T <= 20 (3T+1 <= 63 lanes), virtual
+// speed rows for 21 <= T <= 31; four wavefronts per ego (two lanes per row) for T = 32 and 40 (half rows in panels of eight).  The
+// kernels are templates on T, fully unrolled -- a horizon is fast if it is in one of these lists (7 s of compile time per
+// instantiation) and runs on the LDS kernel otherwise (any T <= 48; 4-6 x slower: tools/dev/horizon_ab.py).  BASELINE.json's
+// configurations use 13 (the reference's stock horizon), 20, 30 and 40; the others are there so that a horizon near them does not
+// fall off that cliff.  Mirrored by config.ONE_WAVE_HORIZONS / FOUR_WAVE_HORIZONS (tests/test_host_cpu.py compares the two).
+#define JSIM_ONE_WAVE_HORIZONS(X) X(13) X(15) X(16) X(20) X(25) X(30)
+#define JSIM_FOUR_WAVE_HORIZONS(X) X(32) X(40)
+#if defined(JSIM_DEV_NO_REG)
+static bool has_reg_kernel(int) { return false; }
+#elif defined(JSIM_DEV_ONLY_T40)
+static bool has_reg_kernel(int T) { return T == 40; }
+#elif defined(JSIM_DEV_ONLY_T30)
+static bool has_reg_kernel(int T) { return T == 30; }
+#elif defined(JSIM_DEV_ONLY_T20)
+static bool has_reg_kernel(int T) { return T == 20; }
+#else
+static bool has_reg_kernel(int T)
+{
+#define JSIM_X(t) if (T == t) return true;
+    JSIM_ONE_WAVE_HORIZONS(JSIM_X) JSIM_FOUR_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
+    return false;
+}
+#endif
 static bool has_fused_glue(int T) { return has_reg_kernel(T); }
 
 static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K, const PreK *Q = nullptr)
@@ -1101,17 +1131,24 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     return;
 #else
     if (Q) { // the loop glue inside the launch
-        if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
-        else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, true>), dim3(B), dim3(256), 0, s, P, K, *Q);
+#define JSIM_X(t) if (T == t) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q); return; }
+        JSIM_ONE_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
+#define JSIM_X(t) if (T == t) { hipLaunchKernelGGL((mpc_step_reg4_kernel<t, true>), dim3(B), dim3(256), 0, s, P, K, *Q); return; }
+        JSIM_FOUR_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
         return;
     }
-    if (T == 13) hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 2>), dim3(B), dim3(64), 0, s, P, K, none);
-    else if (T == 20 && B >= w2_min_b) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none);
-    else if (T == 20) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
-    else if (T == 30) hipLaunchKernelGGL((mpc_step_reg_kernel<30, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
-    else if (T == 40) hipLaunchKernelGGL((mpc_step_reg4_kernel<40, false>), dim3(B), dim3(256), 0, s, P, K, none);
+    // register budgets (WPE): T = 13 fits 256 registers without scratch -- two waves per SIMD at every batch size; T = 20 has a
+    // 256-register form for batches above one ego per SIMD; every other horizon one wave per SIMD
+    if (T == 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
+    if (T == 20 && B >= w2_min_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
+#define JSIM_X(t) if (T == t && t != 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, false, (t == 13 ? 2 : 1)>), dim3(B), dim3(64), 0, s, P, K, none); return; }
+    JSIM_ONE_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
+#define JSIM_X(t) if (T == t) { hipLaunchKernelGGL((mpc_step_reg4_kernel<t, false>), dim3(B), dim3(256), 0, s, P, K, none); return; }
+    JSIM_FOUR_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
 #endif
 }
 

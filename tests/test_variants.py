@@ -150,11 +150,11 @@ def test_sensitivity_dropin_rereads_its_json(pkg, oracle, routes, tmp_path, monk
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T", (20, 30, 40, 25))
+@pytest.mark.parametrize("T", (20, 30, 40, 24))
 def test_per_ego_weights_one_batch(pkg, oracle, routes, T):
     """A sensitivity sweep as one launch: every ego of the batch carries its own weights and limits
-    (jsim_mpc_set_ego_config).  T = 20 / 30 / 40 / 25 = the one-wave kernel with resident and with virtual speed
-    rows, the two-wave kernel and the LDS kernel.  Each ego against the oracle run
+    (jsim_mpc_set_ego_config).  T = 20 / 30 / 40 / 24 = the one-wave kernel with resident and with virtual speed
+    rows, the four-wave kernel and the LDS kernel.  Each ego against the oracle run
     with that ego's parameters; switching the table off restores the engine's configuration."""
     from dataclasses import replace
     B = 48
