@@ -239,7 +239,7 @@ class ScenarioLoop:
         self.obst.get(step=True)
 
     def run(self, n_ticks: int):
-        """n_ticks ticks in one call (jsim_loop_run_scenario).  With a register kernel (T = 13, 20, 30, 40) and MAX_ITER = 1
+        """n_ticks ticks in one call (jsim_loop_run_scenario).  With a register kernel (config.ONE_WAVE_HORIZONS / FOUR_WAVE_HORIZONS) and MAX_ITER = 1
         three launches -- the scripted obstacles rolled forward n_ticks ticks, their predictions for every
         tick, and one fused launch in which each ego's wavefront does glue + solve + plant n_ticks times.  Same results as
         n_ticks x tick()."""

@@ -165,7 +165,7 @@ int jsim_loop_set_geometry(jsim_ctx *ctx, double cc_front, double cc_rear, doubl
  * (traj_idx, prev_path_len in/out; path_len, col_flag, pre_status out) and jsim_loop_obstacles (obs_state in/out, obs_param,
  * obs_get [n_obs][6] out).  speed_cutoff = 1: the glue of main/scenarios/mpc_intersection_new_ref.py:122-139 -- the path
  * stays whole (path_len must hold the full lengths) and the cut-off index goes to the buffer registered with
- * jsim_mpc_set_speed_cutoff.  With a register kernel (T = 13, 20, 30, 40) and MAX_ITER = 1 it is three launches: obstacles rolled forward n_ticks ticks, their predictions for
+ * jsim_mpc_set_speed_cutoff.  With a register kernel (T = 13, 15, 16, 20, 25, 30, 32, 40) and MAX_ITER = 1 it is three launches: obstacles rolled forward n_ticks ticks, their predictions for
  * every tick, and ONE fused launch in which every ego's wave runs its own glue + solve + plant n_ticks times; otherwise the
  * same ticks as separate launches.  Identical results either way. */
 int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks, double *x0, const int32_t *path_id, int32_t *path_len,
