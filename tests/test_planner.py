@@ -270,3 +270,58 @@ def test_hip_planner_on_the_references_other_scenarios(pkg):
         np.testing.assert_allclose(r.nodes, g[f"r{i}_path"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(r.trajectory, g[f"r{i}_traj"], rtol=0, atol=1e-9)
     assert none >= 10 and worst >= 10000
+
+
+def _random_field_queries(pkg, g):
+    PL = pkg.planner
+    qs = []
+    for i in range(int(g["n_routes"])):
+        off = g[f"r{i}_hp_off"]
+        qs.append(PL.RouteQuery(start=tuple(g[f"r{i}_start"]), goal=tuple(g[f"r{i}_goal"]), goal_box=tuple(g[f"r{i}_goal_box"]),
+                                tol=float(g[f"r{i}_tol"]), obstacles=[g[f"r{i}_hp"][off[k]:off[k + 1]] for k in range(len(off) - 1)]))
+    return qs
+
+
+def test_random_field_fixture_is_the_oracles(pkg):
+    """tests/golden/planner_random.npz holds the ORACLE's routes on random obstacle fields (make_golden_planner_random.py): the
+    cheapest of them are solved again here, bit for bit; the car geometry in the file is the product's."""
+    import planner_oracle as PO
+    g = load_golden("planner_random.npz")
+    rad, cen = pkg.planner.car_circles()
+    assert rad == float(g["radius"]) and np.array_equal(cen, g["circle_centers"])
+    qs = _random_field_queries(pkg, g)
+    cheap = [i for i in range(len(qs)) if int(g[f"r{i}_n_expanded"]) <= 100]
+    assert len(cheap) >= 8 and len(qs) >= 20
+    for i in cheap:
+        q = qs[i]
+        orc = PO.PlannerOracle(q.start, q.goal, q.goal_box, q.tol, q.obstacles, PO.make_motion_primitives(), cen, rad)
+        cost, path, traj = orc.run()
+        assert cost == float(g[f"r{i}_cost"]) and orc.n_expanded == int(g[f"r{i}_n_expanded"]) and orc.max_open == int(g[f"r{i}_max_open"])
+        assert orc.prim_sequence(path) == list(g[f"r{i}_prims"]) and np.array_equal(traj, g[f"r{i}_traj"])
+
+
+@pytest.mark.gpu
+def test_hip_planner_on_random_obstacle_fields(pkg):
+    """21 searches through random fields of 7-16 boxes and octagons, free space around them: open lists of up to 31k entries (the
+    64-ary heap's third level, beyond LDS), up to 4k expansions, dead ends, stale pops and key ties that the corridors of the
+    reference's scenarios do not produce.  One launch; every route against the oracle's (same primitive at every step, cost /
+    nodes / trajectory <= 1e-9, expansion counts within the tie level); and the same with a node table the longest searches
+    outgrow, which sends them through the second attempt."""
+    g = load_golden("planner_random.npz")
+    qs = _random_field_queries(pkg, g)
+    PL = pkg.planner
+    for kw in (dict(), dict(node_cap=4096, retry_node_cap=1 << 17)):
+        res = PL.plan_routes(qs, **kw)
+        worst_open = 0
+        for i, r in enumerate(res):
+            ne = int(g[f"r{i}_n_expanded"])
+            assert r.status == 0, (i, r.status)
+            assert list(r.prims) == list(g[f"r{i}_prims"]), i
+            assert abs(r.n_expanded - ne) <= max(1, ne // 50), (i, r.n_expanded, ne)
+            assert abs(r.cost - float(g[f"r{i}_cost"])) <= 1e-9 * max(1.0, abs(float(g[f"r{i}_cost"])))
+            np.testing.assert_allclose(r.nodes, g[f"r{i}_path"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(r.trajectory, g[f"r{i}_traj"], rtol=0, atol=1e-9)
+            worst_open = max(worst_open, int(g[f"r{i}_max_open"]))
+        assert worst_open > 3 * 4161          # (the fixture does reach the part of the open list that lives in global memory)
+    first = PL.plan_routes(qs, node_cap=4096, retry_node_cap=0)
+    assert sum(r.status == 4 for r in first) >= 4 and all(r.status in (0, 4) for r in first)
