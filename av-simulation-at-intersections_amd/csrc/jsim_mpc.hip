@@ -1107,8 +1107,10 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     static const PreK none = {};
     // more egos than SIMDs (256 CUs x 4): the T = 20 form built for two waves per SIMD (mpc_step_reg.inc, WPE)
     static const int w2_min_b = [] { const char *e = getenv("JSIM_W2_MIN_B"); return e ? atoi(e) : 1025; }();
+    // at most one ego per CU (256 CUs): the T = 20 form with three helper wavefronts per ego (mpc_step_reg.inc, HELP)
+    static const int help_max_b = [] { const char *e = getenv("JSIM_HELP_MAX_B"); return e ? atoi(e) : 256; }();
 #if defined(JSIM_DEV_NO_REG) /* development builds of the planner / glue: no register kernel is instantiated */
-    (void)T; (void)B; (void)s; (void)P; (void)K; (void)Q; (void)none; (void)w2_min_b;
+    (void)T; (void)B; (void)s; (void)P; (void)K; (void)Q; (void)none; (void)w2_min_b; (void)help_max_b;
     return;
 #elif defined(JSIM_DEV_ONLY_T40) /* development builds: only the T = 40 kernel is instantiated (seconds instead of minutes to compile) */
     if (T == 40) {
@@ -1125,6 +1127,7 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
 #elif defined(JSIM_DEV_ONLY_T20) /* development builds: only the T = 20 one-wave kernels */
     if (T == 20) {
         if (Q) hipLaunchKernelGGL((mpc_step_reg_kernel<20, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q);
+        else if (B <= help_max_b) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none);
         else if (B >= w2_min_b) hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none);
         else hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1>), dim3(B), dim3(64), 0, s, P, K, none);
     }
@@ -1142,6 +1145,7 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     // register budgets (WPE): T = 13 fits 256 registers without scratch -- two waves per SIMD at every batch size; T = 20 has a
     // 256-register form for batches above one ego per SIMD; every other horizon one wave per SIMD
     if (T == 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
+    if (T == 20 && B <= help_max_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none); return; }
     if (T == 20 && B >= w2_min_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
 #define JSIM_X(t) if (T == t && t != 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, false, (t == 13 ? 2 : 1)>), dim3(B), dim3(64), 0, s, P, K, none); return; }
     JSIM_ONE_WAVE_HORIZONS(JSIM_X)

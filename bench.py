@@ -59,6 +59,8 @@ def kernel_name(T, scenario, B):
     import importlib
     cfg = importlib.import_module("av-simulation-at-intersections_amd.config")
     if T in cfg.ONE_WAVE_HORIZONS:
+        if T == 20 and not scenario and B <= 256:           # one ego per CU at most: three helper wavefronts per ego (HELP)
+            return "mpc_step_reg_kernel<20, false, 1, true>"
         wpe = 2 if (not scenario and (T == 13 or (T == 20 and B > 1024))) else 1
         return f"mpc_step_reg_kernel<{T}, {pre}, {wpe}>"
     if T in cfg.FOUR_WAVE_HORIZONS:
@@ -337,7 +339,8 @@ def main():
                 traffic_source = (f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc passes of this command "
                                   f"({pmc.get('ticks_per_launch', 100)} ticks per launch, library at commit {pmc.get('commit', '?')}), "
                                   f"scaled to {tpl} ticks; stale if the kernel changed since")
-        waves = 4 if T == 40 else 1
+        kname = kernel_name(T, cfg["scenario"], B)
+        waves = 4 if "reg4" in kname else "1 + 3 helper" if kname.endswith(", true>") and "reg_kernel" in kname and kname.count(",") == 3 else 1
         per_simd = 2 if kernel_name(T, cfg["scenario"], B).endswith(", 2>") else 1
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",

@@ -224,7 +224,7 @@ def test_bench_line_fields():
     assert s["max_ego_iters_per_tick"] >= cfg["mean_active_set_iters"] and s["slowest_over_mean"] >= 1.0
     o = j["other_respawn_rule"]
     assert o["respawn"] == "start" and o["value"] > 0 and o["straggler"]["slowest_over_mean"] >= 1.0
-    assert j["roofline"]["kernel"] == "mpc_step_reg_kernel<20, false, 1>"
+    assert j["roofline"]["kernel"] == "mpc_step_reg_kernel<20, false, 1, true>"
     # the flops of the roofline come from the timed launches' own iteration count (SURVEY 8d's formula)
     flops = (16 * 20 ** 3 + 8 * 20 ** 3 / 3 + 40 * 400 * cfg["mean_active_set_iters"] + 32 * 400 + 1200) * 256 * 20
     assert abs(j["roofline"]["algorithmic_flops_per_launch"] / flops - 1.0) < 2e-3 and j["roofline"]["ticks_per_launch"] == 20

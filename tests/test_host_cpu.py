@@ -313,13 +313,14 @@ def test_bench_line_helpers():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert bench.kernel_name(40, False, 1024) == "mpc_step_reg4_kernel<40, false>" and bench.kernel_name(40, True, 64) == "mpc_step_reg4_kernel<40, true>"
-    assert bench.kernel_name(20, False, 256) == "mpc_step_reg_kernel<20, false, 1>" and bench.kernel_name(20, False, 1024) == "mpc_step_reg_kernel<20, false, 1>"
+    assert bench.kernel_name(20, False, 256) == "mpc_step_reg_kernel<20, false, 1, true>" and bench.kernel_name(20, False, 1024) == "mpc_step_reg_kernel<20, false, 1>"
+    assert bench.kernel_name(20, False, 257) == "mpc_step_reg_kernel<20, false, 1>" and bench.kernel_name(20, True, 64) == "mpc_step_reg_kernel<20, true, 1>"
     assert bench.kernel_name(20, False, 1025) == "mpc_step_reg_kernel<20, false, 2>" and bench.kernel_name(20, True, 4096) == "mpc_step_reg_kernel<20, true, 1>"
     assert bench.kernel_name(13, False, 8) == "mpc_step_reg_kernel<13, false, 2>" and bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>"
     assert bench.kernel_name(25, False, 8) == "mpc_step_reg_kernel<25, false, 1>" and bench.kernel_name(32, True, 8) == "mpc_step_reg4_kernel<32, true>"
     assert bench.kernel_name(24, False, 8) == "mpc_step_kernel" and bench.kernel_name(48, False, 8) == "mpc_step_kernel"
     src = open(os.path.join(REPO, "av-simulation-at-intersections_amd", "csrc", "jsim_mpc.hip")).read()
-    assert "return e ? atoi(e) : 1025;" in src                      # the dispatch threshold kernel_name() mirrors
+    assert "return e ? atoi(e) : 1025;" in src and "return e ? atoi(e) : 256;" in src   # the dispatch thresholds kernel_name() mirrors
     # the horizon lists kernel_name() reads are the library's own
     import re
     cfg = importlib.import_module("av-simulation-at-intersections_amd.config")
