@@ -1144,6 +1144,7 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     }
     // register budgets (WPE): T = 13 fits 256 registers without scratch -- two waves per SIMD at every batch size; T = 20 has a
     // 256-register form for batches above one ego per SIMD; every other horizon one wave per SIMD
+    if (T == 13 && B <= help_max_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none); return; }
     if (T == 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
     if (T == 20 && B <= help_max_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none); return; }
     if (T == 20 && B >= w2_min_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }

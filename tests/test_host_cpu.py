@@ -316,7 +316,8 @@ def test_bench_line_helpers():
     assert bench.kernel_name(20, False, 256) == "mpc_step_reg_kernel<20, false, 1, true>" and bench.kernel_name(20, False, 1024) == "mpc_step_reg_kernel<20, false, 1>"
     assert bench.kernel_name(20, False, 257) == "mpc_step_reg_kernel<20, false, 1>" and bench.kernel_name(20, True, 64) == "mpc_step_reg_kernel<20, true, 1>"
     assert bench.kernel_name(20, False, 1025) == "mpc_step_reg_kernel<20, false, 2>" and bench.kernel_name(20, True, 4096) == "mpc_step_reg_kernel<20, true, 1>"
-    assert bench.kernel_name(13, False, 8) == "mpc_step_reg_kernel<13, false, 2>" and bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>"
+    assert bench.kernel_name(13, False, 8) == "mpc_step_reg_kernel<13, false, 1, true>" and bench.kernel_name(13, False, 257) == "mpc_step_reg_kernel<13, false, 2>"
+    assert bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>" and bench.kernel_name(30, False, 8) == "mpc_step_reg_kernel<30, false, 1>"
     assert bench.kernel_name(25, False, 8) == "mpc_step_reg_kernel<25, false, 1>" and bench.kernel_name(32, True, 8) == "mpc_step_reg4_kernel<32, true>"
     assert bench.kernel_name(24, False, 8) == "mpc_step_kernel" and bench.kernel_name(48, False, 8) == "mpc_step_kernel"
     src = open(os.path.join(REPO, "av-simulation-at-intersections_amd", "csrc", "jsim_mpc.hip")).read()
