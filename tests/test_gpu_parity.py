@@ -273,6 +273,42 @@ def test_fused_ticks_equal_single_ticks(pkg, routes, T):
     assert int(l1.n_respawn.item()) == int(l2.n_respawn.item()) > 0
 
 
+@pytest.mark.parametrize("T", (13, 20))
+def test_helper_wavefronts_change_nothing(pkg, routes, T):
+    """Up to 256 egos run on the kernel with three helper wavefronts per ego (mpc_step_reg_kernel<T, false, 1, true>: the scan of S1,
+    tile rows of H, g and J = L^-T are done by the helpers), larger batches on the one-wave kernel.  Same operations in the same
+    order: the same 256 egos alone and as the first 256 of a batch of 320 -- truncated and 3-point paths, infeasible starts
+    (the owner's early exits, which must release the helpers) among them -- through 40 closed-loop ticks with respawns, every
+    recorded control, state, index, active set and iteration count bit for bit; single steps likewise."""
+    K, B1, B2 = 40, 256, 320
+    big = pkg.synth.make_ego_batch(routes, B2, T, seed=23, truncate=True, near_end_frac=0.4)
+    big.x0[5, 2] = 9.5                                  # v0 > speed: the reference's failure path
+    big.x0[6, 2] = -5.5                                 # v0 < MIN_SPEED
+    big.path_len[7] = big.target_ind[7] + 2             # two points left: no scan
+    big.path_len[8] = big.target_ind[8] + 3             # three points left: the shortest scan
+    small = pkg.synth.EgoBatch(**{k: getattr(big, k)[:B1].copy() for k in ("x0", "path_id", "path_len", "target_ind", "speed", "oa", "od")})
+    out = []
+    for b in (small, big):
+        eng = _engine(pkg, routes, b, T)
+        loop = pkg.ClosedLoop(eng, torch.from_numpy(b.x0).to(eng.device), hist_cap=K, max_age=25)
+        loop.run(K // 2); loop.run(K - K // 2)
+        torch.cuda.synchronize()
+        out.append((eng, loop))
+    (e1, l1), (e2, l2) = out
+    assert torch.equal(l1.hist[:K], l2.hist[:K, :B1]) and torch.equal(l1.x0, l2.x0[:B1]) and torch.equal(l1.age, l2.age[:B1])
+    for name in ("oa", "od", "ox", "oy", "ov", "oyaw", "xref", "target_ind", "status", "n_iter", "active_mask", "di_ai"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)[:B1]), name
+    assert int(l1.n_respawn.item()) > 0
+    s1, s2 = _engine(pkg, routes, small, T), _engine(pkg, routes, big, T)       # one step, debug outputs included
+    d1, d2 = _debug_bufs(s1), _debug_bufs(s2)
+    s1.solve(torch.from_numpy(small.x0).to(s1.device), debug=d1)
+    s2.solve(torch.from_numpy(big.x0).to(s2.device), debug=d2)
+    torch.cuda.synchronize()
+    for k in d1:
+        assert torch.equal(d1[k], d2[k][:B1]), k
+    assert torch.equal(s1.status, s2.status[:B1]) and (s1.status == 1).sum().item() >= 2
+
+
 @pytest.mark.parametrize("T", (13, 20, 30, 40))
 def test_lds_kernel_and_register_kernel_agree(pkg, oracle, routes, T, monkeypatch):
     """T = 13 / 20 / 30 / 40 normally run a register-resident kernel (one or two wavefronts per ego);
