@@ -14,6 +14,7 @@ DEFAULT_CONFIG_PATH = os.path.join(_HERE, "mpc_config.json")
 # CPU test compares the lists).  Any other T <= 48 runs on the LDS kernel: same results, 4-6 x slower.
 ONE_WAVE_HORIZONS = (13, 15, 16, 20, 25, 30)
 FOUR_WAVE_HORIZONS = (32, 40)
+HELP_HORIZONS = (13, 15, 16, 20, 25)     # one-wave horizons with the three-helper-wavefronts form, taken for batches of up to 256 egos
 
 
 def deg2rad(x: float) -> float:

@@ -1080,9 +1080,13 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 // kernels are templates on T, fully unrolled -- a horizon is fast if it is in one of these lists (7 s of compile time per
 // instantiation) and runs on the LDS kernel otherwise (any T <= 48; 4-6 x slower: tools/dev/horizon_ab.py).  BASELINE.json's
 // configurations use 13 (the reference's stock horizon), 20, 30 and 40; the others are there so that a horizon near them does not
-// fall off that cliff.  Mirrored by config.ONE_WAVE_HORIZONS / FOUR_WAVE_HORIZONS (tests/test_host_cpu.py compares the two).
+// fall off that cliff.  Mirrored by config.ONE_WAVE_HORIZONS / FOUR_WAVE_HORIZONS / HELP_HORIZONS (tests/test_host_cpu.py compares them).
 #define JSIM_ONE_WAVE_HORIZONS(X) X(13) X(15) X(16) X(20) X(25) X(30)
 #define JSIM_FOUR_WAVE_HORIZONS(X) X(32) X(40)
+// one-wave horizons that also have the form with three helper wavefronts per ego, taken at B <= 256 (one ego per CU at most).  Measured
+// at 256 egos, closed loop (tools/dev/help_ab13.py): T = 13 +8 %, 15 +6 %, 16 +11 %, 20 +11-14 %, 25 +6 %; T = 30 LOSES 2 % (448
+// registers, 72 KB of LDS: handing 61 rows of 60 doubles over costs what the helpers save) and is left out.
+#define JSIM_HELP_HORIZONS(X) X(13) X(15) X(16) X(20) X(25)
 #if defined(JSIM_DEV_NO_REG)
 static bool has_reg_kernel(int) { return false; }
 #elif defined(JSIM_DEV_ONLY_T40)
@@ -1144,9 +1148,13 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     }
     // register budgets (WPE): T = 13 fits 256 registers without scratch -- two waves per SIMD at every batch size; T = 20 has a
     // 256-register form for batches above one ego per SIMD; every other horizon one wave per SIMD
-    if (T == 13 && B <= help_max_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none); return; }
+    // at most one ego per CU: three helper wavefronts per ego (mpc_step_reg.inc, HELP) -- every one-wave horizon
+    if (B <= help_max_b) {
+#define JSIM_X(t) if (T == t) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none); return; }
+        JSIM_HELP_HORIZONS(JSIM_X)
+#undef JSIM_X
+    }
     if (T == 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<13, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
-    if (T == 20 && B <= help_max_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 1, true>), dim3(B), dim3(256), 0, s, P, K, none); return; }
     if (T == 20 && B >= w2_min_b) { hipLaunchKernelGGL((mpc_step_reg_kernel<20, false, 2>), dim3(B), dim3(64), 0, s, P, K, none); return; }
 #define JSIM_X(t) if (T == t && t != 13) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, false, (t == 13 ? 2 : 1)>), dim3(B), dim3(64), 0, s, P, K, none); return; }
     JSIM_ONE_WAVE_HORIZONS(JSIM_X)

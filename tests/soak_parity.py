@@ -31,7 +31,7 @@ for r in routes:
     S.smooth_yaw_inplace(r[:, 2])
 cx, cy, cyaw, off = S.pack_paths(routes)
 bad = 0
-for T in (13, 20, 30, 40, 25):
+for T in (13, 15, 16, 20, 25, 30, 32, 40, 24):   # every horizon with a register kernel + one on the LDS kernel
     worst = 0.0
     n_mask = n_stat = n_tind = n_ego = 0
     same_it = 0

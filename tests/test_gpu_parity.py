@@ -273,7 +273,7 @@ def test_fused_ticks_equal_single_ticks(pkg, routes, T):
     assert int(l1.n_respawn.item()) == int(l2.n_respawn.item()) > 0
 
 
-@pytest.mark.parametrize("T", (13, 20))
+@pytest.mark.parametrize("T", (13, 20, 15, 16, 25))     # config.HELP_HORIZONS
 def test_helper_wavefronts_change_nothing(pkg, routes, T):
     """Up to 256 egos run on the kernel with three helper wavefronts per ego (mpc_step_reg_kernel<T, false, 1, true>: the scan of S1,
     tile rows of H, g and J = L^-T are done by the helpers), larger batches on the one-wave kernel.  Same operations in the same

@@ -318,14 +318,14 @@ def test_bench_line_helpers():
     assert bench.kernel_name(20, False, 1025) == "mpc_step_reg_kernel<20, false, 2>" and bench.kernel_name(20, True, 4096) == "mpc_step_reg_kernel<20, true, 1>"
     assert bench.kernel_name(13, False, 8) == "mpc_step_reg_kernel<13, false, 1, true>" and bench.kernel_name(13, False, 257) == "mpc_step_reg_kernel<13, false, 2>"
     assert bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>" and bench.kernel_name(30, False, 8) == "mpc_step_reg_kernel<30, false, 1>"
-    assert bench.kernel_name(25, False, 8) == "mpc_step_reg_kernel<25, false, 1>" and bench.kernel_name(32, True, 8) == "mpc_step_reg4_kernel<32, true>"
+    assert bench.kernel_name(25, False, 8) == "mpc_step_reg_kernel<25, false, 1, true>" and bench.kernel_name(25, False, 300) == "mpc_step_reg_kernel<25, false, 1>" and bench.kernel_name(32, True, 8) == "mpc_step_reg4_kernel<32, true>"
     assert bench.kernel_name(24, False, 8) == "mpc_step_kernel" and bench.kernel_name(48, False, 8) == "mpc_step_kernel"
     src = open(os.path.join(REPO, "av-simulation-at-intersections_amd", "csrc", "jsim_mpc.hip")).read()
     assert "return e ? atoi(e) : 1025;" in src and "return e ? atoi(e) : 256;" in src   # the dispatch thresholds kernel_name() mirrors
     # the horizon lists kernel_name() reads are the library's own
     import re
     cfg = importlib.import_module("av-simulation-at-intersections_amd.config")
-    for macro, lst in (("JSIM_ONE_WAVE_HORIZONS", cfg.ONE_WAVE_HORIZONS), ("JSIM_FOUR_WAVE_HORIZONS", cfg.FOUR_WAVE_HORIZONS)):
+    for macro, lst in (("JSIM_ONE_WAVE_HORIZONS", cfg.ONE_WAVE_HORIZONS), ("JSIM_FOUR_WAVE_HORIZONS", cfg.FOUR_WAVE_HORIZONS), ("JSIM_HELP_HORIZONS", cfg.HELP_HORIZONS)):
         line = re.search(r"#define %s\(X\)(.*)" % macro, src).group(1)
         assert tuple(int(t) for t in re.findall(r"X\((\d+)\)", line)) == tuple(lst), macro
     mean, s = bench.straggler_stats(np.array([100, 100, 100, 700], dtype=np.uint64), 10)
