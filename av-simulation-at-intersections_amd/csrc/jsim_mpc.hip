@@ -1111,8 +1111,22 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     static const PreK none = {};
     // more egos than SIMDs (256 CUs x 4): the T = 20 form built for two waves per SIMD (mpc_step_reg.inc, WPE)
     static const int w2_min_b = [] { const char *e = getenv("JSIM_W2_MIN_B"); return e ? atoi(e) : 1025; }();
-    // at most one ego per CU (256 CUs): the T = 20 form with three helper wavefronts per ego (mpc_step_reg.inc, HELP)
-    static const int help_max_b = [] { const char *e = getenv("JSIM_HELP_MAX_B"); return e ? atoi(e) : 256; }();
+    // at most one ego per CU: the form with three helper wavefronts per ego (mpc_step_reg.inc, HELP) -- it needs a CU to itself (four
+    // wavefronts of 270-350 registers), so the default threshold is the device's CU count (256 on an MI355X in SPX mode)
+    static const int help_env_b = [] { const char *e = getenv("JSIM_HELP_MAX_B"); return e ? atoi(e) : -1; }();
+    int help_max_b = help_env_b;
+    if (help_max_b < 0) {
+        static int cus[64];   // per device id, 0 = not asked yet
+        int dev = 0;
+        help_max_b = 256;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (cus[dev] == 0) {
+                int n = 0;
+                cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+            }
+            help_max_b = cus[dev];
+        }
+    }
 #if defined(JSIM_DEV_NO_REG) /* development builds of the planner / glue: no register kernel is instantiated */
     (void)T; (void)B; (void)s; (void)P; (void)K; (void)Q; (void)none; (void)w2_min_b; (void)help_max_b;
     return;
