@@ -309,6 +309,38 @@ def test_helper_wavefronts_change_nothing(pkg, routes, T):
     assert torch.equal(s1.status, s2.status[:B1]) and (s1.status == 1).sum().item() >= 2
 
 
+@pytest.mark.parametrize("T", (13, 20))
+def test_garbage_states_neither_stall_nor_leak(pkg, routes, T):
+    """Egos whose state is garbage (NaN, inf, 1e200) beside sane ones, on the kernel with helper wavefronts: the helpers wait for the
+    owner's columns by polling LDS, so whatever the owner's arithmetic turns into must still release them (a bounded wait that runs
+    out costs a quarter of a second per column) -- the closed loop finishes promptly, and the sane egos' results are those of a batch
+    without the garbage."""
+    import time
+    B, K = 96, 12
+    clean = pkg.synth.make_ego_batch(routes, B, T, seed=31, truncate=True)
+    dirty = pkg.synth.EgoBatch(**{k: getattr(clean, k).copy() for k in ("x0", "path_id", "path_len", "target_ind", "speed", "oa", "od")})
+    bad = [3, 17, 40, 41]
+    dirty.x0[3, 0] = np.nan
+    dirty.x0[17, 2] = np.inf
+    dirty.x0[40, :2] = 1e200
+    dirty.x0[41, 3] = -np.inf
+    dirty.oa[17, :] = 1e300
+    out = []
+    for b in (clean, dirty):
+        eng = _engine(pkg, routes, b, T)
+        loop = pkg.ClosedLoop(eng, torch.from_numpy(b.x0).to(eng.device), hist_cap=K, max_age=400)
+        loop.run(1); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.run(K - 1)
+        torch.cuda.synchronize()
+        out.append((eng, loop, time.perf_counter() - t0))
+    (e1, l1, t1), (e2, l2, t2) = out
+    assert t2 < 1.0, t2                                   # (11 ticks take ~1 ms; one exhausted wait alone is 0.25 s)
+    good = np.setdiff1d(np.arange(B), bad)
+    assert torch.equal(l1.hist[:K, good], l2.hist[:K, good]) and torch.equal(l1.x0[good], l2.x0[good])
+    assert torch.equal(e1.status[good], e2.status[good]) and torch.equal(e1.oa[good], e2.oa[good])
+
+
 @pytest.mark.parametrize("T", (13, 20, 30, 40))
 def test_lds_kernel_and_register_kernel_agree(pkg, oracle, routes, T, monkeypatch):
     """T = 13 / 20 / 30 / 40 normally run a register-resident kernel (one or two wavefronts per ego);
