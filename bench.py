@@ -68,6 +68,15 @@ def kernel_name(T, scenario, B):
     return "mpc_step_kernel"
 
 
+def waves_per_ego(kname):
+    """Wavefronts that work on one ego in the kernel kernel_name() returned (for the roofline note)."""
+    if "reg4" in kname:
+        return 4
+    if kname.startswith("mpc_step_reg_kernel<") and kname.count(",") == 3 and kname.endswith(", true>"):
+        return "1 + 3 helper"
+    return 1
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,7 +349,7 @@ def main():
                                   f"({pmc.get('ticks_per_launch', 100)} ticks per launch, library at commit {pmc.get('commit', '?')}), "
                                   f"scaled to {tpl} ticks; stale if the kernel changed since")
         kname = kernel_name(T, cfg["scenario"], B)
-        waves = 4 if "reg4" in kname else "1 + 3 helper" if kname.endswith(", true>") and "reg_kernel" in kname and kname.count(",") == 3 else 1
+        waves = waves_per_ego(kname)
         per_simd = 2 if kernel_name(T, cfg["scenario"], B).endswith(", 2>") else 1
         out = {
             "metric": "MPC steps/sec (batch x horizon) at N=20 nu=2",

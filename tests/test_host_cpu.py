@@ -320,6 +320,8 @@ def test_bench_line_helpers():
     assert bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>" and bench.kernel_name(30, False, 8) == "mpc_step_reg_kernel<30, false, 1>"
     assert bench.kernel_name(25, False, 8) == "mpc_step_reg_kernel<25, false, 1, true>" and bench.kernel_name(25, False, 300) == "mpc_step_reg_kernel<25, false, 1>" and bench.kernel_name(32, True, 8) == "mpc_step_reg4_kernel<32, true>"
     assert bench.kernel_name(24, False, 8) == "mpc_step_kernel" and bench.kernel_name(48, False, 8) == "mpc_step_kernel"
+    assert bench.waves_per_ego(bench.kernel_name(20, False, 256)) == "1 + 3 helper" and bench.waves_per_ego(bench.kernel_name(20, True, 256)) == 1
+    assert bench.waves_per_ego(bench.kernel_name(40, False, 8)) == 4 and bench.waves_per_ego(bench.kernel_name(20, False, 4096)) == 1
     src = open(os.path.join(REPO, "av-simulation-at-intersections_amd", "csrc", "jsim_mpc.hip")).read()
     assert "return e ? atoi(e) : 1025;" in src and "hipDeviceAttributeMultiprocessorCount" in src   # the dispatch thresholds kernel_name() mirrors (256 CUs)
     # the horizon lists kernel_name() reads are the library's own
