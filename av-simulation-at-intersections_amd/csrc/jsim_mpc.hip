@@ -1087,6 +1087,44 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 // at 256 egos, closed loop (tools/dev/help_ab13.py): T = 13 +8 %, 15 +6 %, 16 +11 %, 20 +11-14 %, 25 +6 %; T = 30 LOSES 2 % (448
 // registers, 72 KB of LDS: handing 61 rows of 60 doubles over costs what the helpers save) and is left out.
 #define JSIM_HELP_HORIZONS(X) X(13) X(15) X(16) X(20) X(25)
+
+// ---- Split build (build.py's default: one translation unit per horizon, compiled in parallel -- 3 minutes of one core otherwise).
+// -DJSIM_KERNEL_TU=<T>: this file up to here plus the explicit instantiations of horizon T's register kernels, nothing else.
+// -DJSIM_SPLIT_BUILD  : the rest of the library, with those instantiations declared `extern template` (their host stubs and code
+//                       objects come from the kernel translation units).  Neither: everything in one unit, as before.
+// The `#if` lists below repeat the three horizon lists above (tests/test_host_cpu.py compares them).
+#define JSIM_REG_ARGS const KP, const TickP, const PreK
+#if defined(JSIM_KERNEL_TU)
+#if JSIM_KERNEL_TU == 32 || JSIM_KERNEL_TU == 40                                                            /* four-wave horizons */
+template __global__ void mpc_step_reg4_kernel<JSIM_KERNEL_TU, true>(JSIM_REG_ARGS);
+template __global__ void mpc_step_reg4_kernel<JSIM_KERNEL_TU, false>(JSIM_REG_ARGS);
+#elif JSIM_KERNEL_TU == 13 || JSIM_KERNEL_TU == 15 || JSIM_KERNEL_TU == 16 || JSIM_KERNEL_TU == 20 || JSIM_KERNEL_TU == 25 || JSIM_KERNEL_TU == 30   /* one-wave horizons */
+template __global__ void mpc_step_reg_kernel<JSIM_KERNEL_TU, true, 1, false>(JSIM_REG_ARGS);
+template __global__ void mpc_step_reg_kernel<JSIM_KERNEL_TU, false, (JSIM_KERNEL_TU == 13 ? 2 : 1), false>(JSIM_REG_ARGS);
+#if JSIM_KERNEL_TU == 20
+template __global__ void mpc_step_reg_kernel<20, false, 2, false>(JSIM_REG_ARGS);
+#endif
+#if JSIM_KERNEL_TU == 13 || JSIM_KERNEL_TU == 15 || JSIM_KERNEL_TU == 16 || JSIM_KERNEL_TU == 20 || JSIM_KERNEL_TU == 25                            /* helper-wavefront horizons */
+template __global__ void mpc_step_reg_kernel<JSIM_KERNEL_TU, false, 1, true>(JSIM_REG_ARGS);
+#endif
+#else
+#error "JSIM_KERNEL_TU: not a horizon with a register kernel"
+#endif
+#else /* !JSIM_KERNEL_TU: the library proper */
+#if defined(JSIM_SPLIT_BUILD)
+#define JSIM_X(t) extern template __global__ void mpc_step_reg_kernel<t, true, 1, false>(JSIM_REG_ARGS); \
+                  extern template __global__ void mpc_step_reg_kernel<t, false, (t == 13 ? 2 : 1), false>(JSIM_REG_ARGS);
+JSIM_ONE_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
+extern template __global__ void mpc_step_reg_kernel<20, false, 2, false>(JSIM_REG_ARGS);
+#define JSIM_X(t) extern template __global__ void mpc_step_reg_kernel<t, false, 1, true>(JSIM_REG_ARGS);
+JSIM_HELP_HORIZONS(JSIM_X)
+#undef JSIM_X
+#define JSIM_X(t) extern template __global__ void mpc_step_reg4_kernel<t, true>(JSIM_REG_ARGS); \
+                  extern template __global__ void mpc_step_reg4_kernel<t, false>(JSIM_REG_ARGS);
+JSIM_FOUR_WAVE_HORIZONS(JSIM_X)
+#undef JSIM_X
+#endif
 #if defined(JSIM_DEV_NO_REG)
 static bool has_reg_kernel(int) { return false; }
 #elif defined(JSIM_DEV_ONLY_T40)
@@ -2321,3 +2359,4 @@ extern "C" int jsim_loop_run_scenario(jsim_ctx *ctx, int32_t B, int32_t n_ticks,
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+#endif /* !JSIM_KERNEL_TU */
