@@ -95,6 +95,13 @@ def _build_split(hipcc: str, extra, obj_dir: str, tmp_lib: str, verbose: bool) -
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    # hipcc's other temporaries (bitcode, preprocessed sources, host listings: 140 MB) are of no use once the library is linked;
+    # the concatenated device listing stays (tests/test_isa_guard.py and tools/isa_*.py read it)
+    for name, d, _, _ in procs:
+        shutil.rmtree(d, ignore_errors=True)
+    for f in os.listdir(obj_dir):
+        if f.startswith("jsim_mpc") and f != ASM_NAME:
+            os.remove(os.path.join(obj_dir, f))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
