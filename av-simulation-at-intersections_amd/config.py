@@ -15,6 +15,7 @@ DEFAULT_CONFIG_PATH = os.path.join(_HERE, "mpc_config.json")
 ONE_WAVE_HORIZONS = (13, 15, 16, 20, 25, 30)
 FOUR_WAVE_HORIZONS = (32, 40)
 HELP_HORIZONS = (13, 15, 16, 20, 25)     # one-wave horizons with the three-helper-wavefronts form, taken for batches of up to 256 egos
+HELP_PRE_HORIZONS = (13, 20)             # ... those whose scenario-loop form (the glue inside the launch) has helpers, too
 
 
 def deg2rad(x: float) -> float:

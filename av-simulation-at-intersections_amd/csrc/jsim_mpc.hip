@@ -1087,6 +1087,10 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(const KP Pin)
 // at 256 egos, closed loop (tools/dev/help_ab13.py): T = 13 +8 %, 15 +6 %, 16 +11 %, 20 +11-14 %, 25 +6 %; T = 30 LOSES 2 % (448
 // registers, 72 KB of LDS: handing 61 rows of 60 doubles over costs what the helpers save) and is left out.
 #define JSIM_HELP_HORIZONS(X) X(13) X(15) X(16) X(20) X(25)
+// ... and those whose form with the loop glue inside the launch (PRE) has helpers too: the reference's stock horizon and the headline's.
+// (T = 16 with PRE and helpers is a build the ISA guard refuses -- vector code in front of a join block's exec restore, section 5 fact 6 of
+// DESIGN.md -- and is not instantiated.)
+#define JSIM_HELP_PRE_HORIZONS(X) X(13) X(20)
 
 // ---- Split build (build.py's default: one translation unit per horizon, compiled in parallel -- 3 minutes of one core otherwise).
 // -DJSIM_KERNEL_TU=<T>: this file up to here plus the explicit instantiations of horizon T's register kernels, nothing else.
@@ -1107,6 +1111,9 @@ template __global__ void mpc_step_reg_kernel<20, false, 2, false>(JSIM_REG_ARGS)
 #if JSIM_KERNEL_TU == 13 || JSIM_KERNEL_TU == 15 || JSIM_KERNEL_TU == 16 || JSIM_KERNEL_TU == 20 || JSIM_KERNEL_TU == 25                            /* helper-wavefront horizons */
 template __global__ void mpc_step_reg_kernel<JSIM_KERNEL_TU, false, 1, true>(JSIM_REG_ARGS);
 #endif
+#if JSIM_KERNEL_TU == 13 || JSIM_KERNEL_TU == 20                                                                                                    /* helper-wavefront horizons with the glue */
+template __global__ void mpc_step_reg_kernel<JSIM_KERNEL_TU, true, 1, true>(JSIM_REG_ARGS);
+#endif
 #else
 #error "JSIM_KERNEL_TU: not a horizon with a register kernel"
 #endif
@@ -1119,6 +1126,9 @@ JSIM_ONE_WAVE_HORIZONS(JSIM_X)
 extern template __global__ void mpc_step_reg_kernel<20, false, 2, false>(JSIM_REG_ARGS);
 #define JSIM_X(t) extern template __global__ void mpc_step_reg_kernel<t, false, 1, true>(JSIM_REG_ARGS);
 JSIM_HELP_HORIZONS(JSIM_X)
+#undef JSIM_X
+#define JSIM_X(t) extern template __global__ void mpc_step_reg_kernel<t, true, 1, true>(JSIM_REG_ARGS);
+JSIM_HELP_PRE_HORIZONS(JSIM_X)
 #undef JSIM_X
 #define JSIM_X(t) extern template __global__ void mpc_step_reg4_kernel<t, true>(JSIM_REG_ARGS); \
                   extern template __global__ void mpc_step_reg4_kernel<t, false>(JSIM_REG_ARGS);
@@ -1190,6 +1200,11 @@ static void launch_reg(int T, int B, hipStream_t s, const KP &P, const TickP &K,
     return;
 #else
     if (Q) { // the loop glue inside the launch
+        if (B <= help_max_b) { // (with helper wavefronts, like the plain closed loop below)
+#define JSIM_X(t) if (T == t) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, true, 1, true>), dim3(B), dim3(256), 0, s, P, K, *Q); return; }
+            JSIM_HELP_PRE_HORIZONS(JSIM_X)
+#undef JSIM_X
+        }
 #define JSIM_X(t) if (T == t) { hipLaunchKernelGGL((mpc_step_reg_kernel<t, true, 1>), dim3(B), dim3(64), 0, s, P, K, *Q); return; }
         JSIM_ONE_WAVE_HORIZONS(JSIM_X)
 #undef JSIM_X

@@ -314,24 +314,24 @@ def test_bench_line_helpers():
     spec.loader.exec_module(bench)
     assert bench.kernel_name(40, False, 1024) == "mpc_step_reg4_kernel<40, false>" and bench.kernel_name(40, True, 64) == "mpc_step_reg4_kernel<40, true>"
     assert bench.kernel_name(20, False, 256) == "mpc_step_reg_kernel<20, false, 1, true>" and bench.kernel_name(20, False, 1024) == "mpc_step_reg_kernel<20, false, 1>"
-    assert bench.kernel_name(20, False, 257) == "mpc_step_reg_kernel<20, false, 1>" and bench.kernel_name(20, True, 64) == "mpc_step_reg_kernel<20, true, 1>"
+    assert bench.kernel_name(20, False, 257) == "mpc_step_reg_kernel<20, false, 1>" and bench.kernel_name(20, True, 64) == "mpc_step_reg_kernel<20, true, 1, true>" and bench.kernel_name(16, True, 64) == "mpc_step_reg_kernel<16, true, 1>"
     assert bench.kernel_name(20, False, 1025) == "mpc_step_reg_kernel<20, false, 2>" and bench.kernel_name(20, True, 4096) == "mpc_step_reg_kernel<20, true, 1>"
     assert bench.kernel_name(13, False, 8) == "mpc_step_reg_kernel<13, false, 1, true>" and bench.kernel_name(13, False, 257) == "mpc_step_reg_kernel<13, false, 2>"
     assert bench.kernel_name(30, True, 4096) == "mpc_step_reg_kernel<30, true, 1>" and bench.kernel_name(30, False, 8) == "mpc_step_reg_kernel<30, false, 1>"
     assert bench.kernel_name(25, False, 8) == "mpc_step_reg_kernel<25, false, 1, true>" and bench.kernel_name(25, False, 300) == "mpc_step_reg_kernel<25, false, 1>" and bench.kernel_name(32, True, 8) == "mpc_step_reg4_kernel<32, true>"
     assert bench.kernel_name(24, False, 8) == "mpc_step_kernel" and bench.kernel_name(48, False, 8) == "mpc_step_kernel"
-    assert bench.waves_per_ego(bench.kernel_name(20, False, 256)) == "1 + 3 helper" and bench.waves_per_ego(bench.kernel_name(20, True, 256)) == 1
+    assert bench.waves_per_ego(bench.kernel_name(20, False, 256)) == "1 + 3 helper" and bench.waves_per_ego(bench.kernel_name(20, True, 256)) == "1 + 3 helper" and bench.waves_per_ego(bench.kernel_name(20, True, 4096)) == 1
     assert bench.waves_per_ego(bench.kernel_name(40, False, 8)) == 4 and bench.waves_per_ego(bench.kernel_name(20, False, 4096)) == 1
     src = open(os.path.join(REPO, "av-simulation-at-intersections_amd", "csrc", "jsim_mpc.hip")).read()
     assert "return e ? atoi(e) : 1025;" in src and "hipDeviceAttributeMultiprocessorCount" in src   # the dispatch thresholds kernel_name() mirrors (256 CUs)
     # the horizon lists kernel_name() reads are the library's own
     import re
     cfg = importlib.import_module("av-simulation-at-intersections_amd.config")
-    for macro, lst in (("JSIM_ONE_WAVE_HORIZONS", cfg.ONE_WAVE_HORIZONS), ("JSIM_FOUR_WAVE_HORIZONS", cfg.FOUR_WAVE_HORIZONS), ("JSIM_HELP_HORIZONS", cfg.HELP_HORIZONS)):
+    for macro, lst in (("JSIM_ONE_WAVE_HORIZONS", cfg.ONE_WAVE_HORIZONS), ("JSIM_FOUR_WAVE_HORIZONS", cfg.FOUR_WAVE_HORIZONS), ("JSIM_HELP_HORIZONS", cfg.HELP_HORIZONS), ("JSIM_HELP_PRE_HORIZONS", cfg.HELP_PRE_HORIZONS)):
         line = re.search(r"#define %s\(X\)(.*)" % macro, src).group(1)
         assert tuple(int(t) for t in re.findall(r"X\((\d+)\)", line)) == tuple(lst), macro
     # the split build's per-horizon units: the `#if JSIM_KERNEL_TU == ..` lists and build.py's unit list repeat the same horizons
-    for tag, lst in (("four-wave horizons", cfg.FOUR_WAVE_HORIZONS), ("one-wave horizons", cfg.ONE_WAVE_HORIZONS), ("helper-wavefront horizons", cfg.HELP_HORIZONS)):
+    for tag, lst in (("four-wave horizons", cfg.FOUR_WAVE_HORIZONS), ("one-wave horizons", cfg.ONE_WAVE_HORIZONS), ("helper-wavefront horizons */", cfg.HELP_HORIZONS), ("helper-wavefront horizons with the glue", cfg.HELP_PRE_HORIZONS)):
         line = [ln for ln in src.splitlines() if ln.startswith(("#if JSIM_KERNEL_TU ==", "#elif JSIM_KERNEL_TU ==")) and tag in ln]
         assert len(line) == 1 and tuple(int(t) for t in re.findall(r"JSIM_KERNEL_TU == (\d+)", line[0])) == tuple(lst), tag
     build_mod = importlib.import_module("av-simulation-at-intersections_amd.build")

@@ -131,7 +131,8 @@ def test_shipped_library_has_no_finding(pkg):
     names = set(T.kernels(asm))
     for k in ("_Z19mpc_step_reg_kernelILi13ELb0ELi2ELb0EEv2KP5TickP4PreK", "_Z19mpc_step_reg_kernelILi20ELb0ELi1ELb0EEv2KP5TickP4PreK",
               "_Z19mpc_step_reg_kernelILi20ELb0ELi1ELb1EEv2KP5TickP4PreK", "_Z19mpc_step_reg_kernelILi13ELb0ELi1ELb1EEv2KP5TickP4PreK",
-              "_Z19mpc_step_reg_kernelILi25ELb0ELi1ELb1EEv2KP5TickP4PreK",      # (three helper wavefronts per ego, B <= 256)
+              "_Z19mpc_step_reg_kernelILi25ELb0ELi1ELb1EEv2KP5TickP4PreK", "_Z19mpc_step_reg_kernelILi13ELb1ELi1ELb1EEv2KP5TickP4PreK",
+              "_Z19mpc_step_reg_kernelILi20ELb1ELi1ELb1EEv2KP5TickP4PreK",      # (three helper wavefronts per ego, B <= 256)
               "_Z19mpc_step_reg_kernelILi20ELb0ELi2ELb0EEv2KP5TickP4PreK", "_Z19mpc_step_reg_kernelILi30ELb1ELi1ELb0EEv2KP5TickP4PreK",
               "_Z19mpc_step_reg_kernelILi25ELb0ELi1ELb0EEv2KP5TickP4PreK", "_Z20mpc_step_reg4_kernelILi32ELb1EEv2KP5TickP4PreK",
               "_Z20mpc_step_reg4_kernelILi40ELb0EEv2KP5TickP4PreK"):
